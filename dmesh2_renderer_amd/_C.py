@@ -1,0 +1,354 @@
+"""``_C``-compatible shim over libdm2_hip.so (include/dm2_hip.h).
+
+Exposes the three functions of the reference's pybind module
+``dmesh2_renderer._C`` (ext.cpp:5-9) with identical positional arguments and
+tuple returns:
+
+    render_forward_cuda(...21 args...)  -> 10-tuple   (render.cu:28-195)
+    render_backward_cuda(...31 args...) -> 6-tuple    (render.cu:198-373)
+    generate_render_layers_cuda(...13 args...) -> 2-tuple (render.cu:378-476)
+
+PyTorch is used only as the owner of device memory and of the current stream;
+every computation happens in the HIP library.  There is NO fallback: if the
+library is missing, or tensors are not on a ROCm device, a RuntimeError is
+raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdm2_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+DM2_FLAG_CORRECTED_DV = 1
+SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE = 0, 1, 2, 3
+
+# opt-in flags applied to every call (tests use this for the corrected-gradient mode)
+_flags = 0
+
+_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+
+class RenderDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", _i32), ("P", _i32), ("F", _i32), ("W", _i32), ("H", _i32), ("K", _i32),
+        ("aa_temperature", ctypes.c_float), ("flags", _i32),
+        ("background", _vp), ("patch_min", _vp), ("verts", _vp), ("faces", _vp), ("verts_color", _vp),
+        ("faces_opacity", _vp), ("verts_ndc", _vp), ("verts_image", _vp), ("faces_intense", _vp),
+        ("aa_face_verts", _vp), ("aa_face_edges", _vp), ("aa_face_edges_iszero", _vp),
+        ("aa_face_edges_recip", _vp), ("aa_face_edges_normal", _vp), ("aa_face_edges_normal_c", _vp),
+        ("image_ray_o", _vp), ("image_ray_d", _vp),
+    ]
+
+
+class LayersDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", _i32), ("P", _i32), ("F", _i32), ("T", _i32), ("W", _i32), ("H", _i32), ("L", _i32), ("flags", _i32),
+        ("verts", _vp), ("faces", _vp), ("tets", _vp), ("face_tets", _vp), ("tet_faces", _vp),
+        ("face_existence", _vp), ("verts_ndc", _vp), ("verts_image", _vp), ("image_ray_o", _vp), ("image_ray_d", _vp),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "dm2_abi_version": (ctypes.c_int, []),
+    "dm2_last_error": (ctypes.c_char_p, []),
+    "dm2_scratch_bytes": (_sz, [ctypes.c_int, _i64, _i64]),
+    "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
+    "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
+    "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
+}
+
+
+def load_library(path: str | None = None):
+    """dlopen libdm2_hip.so and bind every symbol include/dm2_hip.h declares."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"dmesh2_renderer_amd: native library not found at {p}; build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C dmesh2_renderer_amd/csrc` "
+                f"(there is no CPU fallback)")
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dm2_abi_version() != 1:
+            raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def set_flags(flags: int):
+    """Set opt-in behaviour flags (DM2_FLAG_*) for subsequent calls; returns the old value."""
+    global _flags
+    old, _flags = _flags, int(flags)
+    return old
+
+
+def _err(lib, what):
+    msg = lib.dm2_last_error()
+    return RuntimeError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "dmesh2_renderer_amd: all tensors must live on a ROCm GPU (got a CPU tensor); "
+                "this build has no CPU path -- the CPU restatement under oracle/ is test infrastructure only")
+    dev = tensors[0].device
+    for t in tensors:
+        if t.device != dev:
+            raise RuntimeError("dmesh2_renderer_amd: tensors are on different devices")
+    return dev
+
+
+def _c(t, dtype):
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")      # packed_accessor64<T> throws likewise
+    return t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _bytes(dev, n):
+    return torch.empty((max(int(n), 0),), dtype=torch.uint8, device=dev)
+
+
+def _check_render_shapes(background, patch_min, verts, faces, verts_color, faces_opacity, verts_ndc, verts_image,
+                         faces_intense, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, ray_o, ray_d, temp, K):
+    # messages of render.cu:62-118
+    def bad(cond, msg):
+        if cond:
+            raise RuntimeError(msg)
+    bad(background.dim() != 1 or background.size(0) != 3, "background must have dimensions (3,)")
+    bad(patch_min.dim() != 2 or patch_min.size(1) != 2, "patch_min must have dimensions (B, 2)")
+    bad(verts.dim() != 2 or verts.size(1) != 3, "verts must have dimensions (P, 3)")
+    bad(faces.dim() != 2 or faces.size(1) != 3, "faces must have dimensions (F, 3)")
+    bad(verts_color.dim() != 2 or verts_color.size(1) != 3, "vert color must have dimensions (P, 3)")
+    bad(faces_opacity.dim() != 1 or faces_opacity.size(0) != faces.size(0), "face opacity must have dimensions (F,)")
+    bad(verts_ndc.dim() != 3 or verts_ndc.size(2) != 3, "verts_ndc must have dimensions (B, P, 3)")
+    bad(verts_image.dim() != 3 or verts_image.size(2) != 2, "verts_image must have dimensions (B, P, 2)")
+    bad(faces_intense.dim() != 2 or faces_intense.size(1) != faces.size(0), "faces_intense must have dimensions (B, F,)")
+    for t, nm in ((aa_v, "aa_face_verts"), (aa_e, "aa_face_edges"), (aa_z, "aa_face_edges_iszero"),
+                  (aa_r, "aa_face_edges_recip"), (aa_n, "aa_face_edges_normal")):
+        bad(t.dim() != 4 or t.size(2) != 3 or t.size(3) != 2, f"{nm} must have dimensions (B, F, 3, 2)")
+    bad(aa_c.dim() != 3 or aa_c.size(2) != 3, "aa_face_edges_normal_c must have dimensions (B, F, 3)")
+    bad(ray_o.dim() != 4 or ray_o.size(3) != 3, "image_ray_o must have dimensions (B, H, W, 3)")
+    bad(ray_d.dim() != 4 or ray_d.size(3) != 3, "image_ray_d must have dimensions (B, H, W, 3)")
+    bad(temp < 0 or temp > 1, "aa_temperature must be in the range [0, 1]")
+    bad(K < 0, "len_oarea_buffer must be non-negative")
+
+
+def _make_desc(args, keep):
+    (background, patch_min, pw, ph, verts, faces, verts_color, faces_opacity, verts_ndc, verts_image, faces_intense,
+     temp, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, K, ray_o, ray_d) = args
+    temp = float(temp); K = int(K); pw = int(pw); ph = int(ph)
+    _check_render_shapes(background, patch_min, verts, faces, verts_color, faces_opacity, verts_ndc, verts_image,
+                         faces_intense, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, ray_o, ray_d, temp, K)
+    dev = _require_gpu(background, patch_min, verts, faces, verts_color, faces_opacity, verts_ndc, verts_image,
+                       faces_intense, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, ray_o, ray_d)
+    f32, i32 = torch.float32, torch.int32
+    B, P, F = verts_ndc.size(0), verts.size(0), faces.size(0)
+    # sizes the kernels index with (the reference's accessors would fault on a mismatch)
+    def need(t, shape, nm):
+        if tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f"{nm} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    need(patch_min, (B, 2), "patch_min"); need(verts_color, (P, 3), "verts_color"); need(verts_ndc, (B, P, 3), "verts_ndc")
+    need(verts_image, (B, P, 2), "verts_image"); need(faces_intense, (B, F), "faces_intense")
+    for t, nm in ((aa_v, "aa_face_verts"), (aa_e, "aa_face_edges"), (aa_z, "aa_face_edges_iszero"),
+                  (aa_r, "aa_face_edges_recip"), (aa_n, "aa_face_edges_normal")):
+        need(t, (B, F, 3, 2), nm)
+    need(aa_c, (B, F, 3), "aa_face_edges_normal_c")
+    need(ray_o, (B, ph, pw, 3), "image_ray_o"); need(ray_d, (B, ph, pw, 3), "image_ray_d")
+    if temp == 0.0:
+        K = 0                                                     # render.cu:141-142
+    ts = dict(
+        background=_c(background, f32), patch_min=_c(patch_min, i32), verts=_c(verts, f32), faces=_c(faces, i32),
+        verts_color=_c(verts_color, f32), faces_opacity=_c(faces_opacity, f32), verts_ndc=_c(verts_ndc, f32),
+        verts_image=_c(verts_image, f32), faces_intense=_c(faces_intense, f32), aa_face_verts=_c(aa_v, f32),
+        aa_face_edges=_c(aa_e, f32), aa_face_edges_iszero=_c(aa_z, torch.bool), aa_face_edges_recip=_c(aa_r, f32),
+        aa_face_edges_normal=_c(aa_n, f32), aa_face_edges_normal_c=_c(aa_c, f32), image_ray_o=_c(ray_o, f32),
+        image_ray_d=_c(ray_d, f32))
+    keep.append(ts)
+    d = RenderDesc()
+    d.B, d.P, d.F, d.W, d.H, d.K = B, P, F, pw, ph, K
+    d.aa_temperature = temp
+    d.flags = _flags
+    for k, t in ts.items():
+        setattr(d, k, t.data_ptr() if t.numel() > 0 else None)
+    return d, dev, (B, P, F, pw, ph, K)
+
+
+def _tiles(B, W, H):
+    return B * ((W + 15) // 16) * ((H + 15) // 16)
+
+
+def render_forward_cuda(*args):
+    """(num_rendered, color, depth, oarea, tri_id, tri_cnt, doarea, face_buffer, binning_buffer, img_buffer).
+
+    The four AA-record tensors and three byte buffers are opaque to callers
+    (reference __init__.py:103-109,160-166).  This implementation recomputes AA
+    overlaps in the backward pass, so ``oarea``/``tri_id``/``doarea`` are empty
+    (B,H,W,0[,3,2]) placeholders; ``tri_cnt`` (B,H,W) holds the number of
+    records the reference would have taken (min(#overlaps visited, K)).
+    """
+    if len(args) != 21:
+        raise TypeError(f"render_forward_cuda() takes 21 positional arguments ({len(args)} given)")
+    lib = load_library()
+    keep: list = []
+    d, dev, (B, P, F, W, H, K) = _make_desc(args, keep)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        f32, i32 = torch.float32, torch.int32
+        color = torch.empty((B, H, W, 3), dtype=f32, device=dev)
+        depth = torch.empty((B, H, W), dtype=f32, device=dev)
+        oarea = torch.empty((B, H, W, 0), dtype=f32, device=dev)
+        tri_id = torch.empty((B, H, W, 0), dtype=i32, device=dev)
+        doarea = torch.empty((B, H, W, 0, 3, 2), dtype=f32, device=dev)
+        N, Tn, BF = B * H * W, _tiles(B, W, H), B * F
+        if P == 0 or BF == 0 or N == 0:
+            # render.cu:149: nothing is rendered; outputs are the zero-initialised images
+            color.zero_(); depth.zero_()
+            tri_cnt = torch.zeros((B, H, W), dtype=i32, device=dev)
+            e = _bytes(dev, 0)
+            return 0, color, depth, oarea, tri_id, tri_cnt, doarea, e, _bytes(dev, 0), _bytes(dev, 0)
+        tri_cnt = torch.empty((B, H, W), dtype=i32, device=dev)
+        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 0))
+        img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_IMAGE, N, Tn))
+        nr = _i64(0)
+        if lib.dm2_forward_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr)):
+            raise _err(lib, "render_forward_cuda (plan)")
+        R = int(nr.value)
+        bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
+        if lib.dm2_forward_run(ctypes.byref(d), R, _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
+                               _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st):
+            raise _err(lib, "render_forward_cuda (run)")
+    return R, color, depth, oarea, tri_id, tri_cnt, doarea, face_buf, bin_buf, img_buf
+
+
+def render_backward_cuda(*args):
+    """-> (dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts).
+
+    The six gradients are views of ONE packed fp32 buffer (attribute
+    ``_dm2_packed`` on the first tensor) so that a multi-GPU caller can sum
+    them with a single RCCL all-reduce (dmesh2_renderer_amd.sharding).
+    """
+    if len(args) != 31:
+        raise TypeError(f"render_backward_cuda() takes 31 positional arguments ({len(args)} given)")
+    lib = load_library()
+    num_rendered = int(args[0])
+    fwd_args = args[1:22]
+    dL_dcolor, dL_ddepth = args[22], args[23]
+    face_buf, bin_buf, img_buf = args[24], args[25], args[26]
+    keep: list = []
+    d, dev, (B, P, F, W, H, K) = _make_desc(fwd_args, keep)
+    _require_gpu(dL_dcolor, dL_ddepth)
+    f32 = torch.float32
+    sizes = [P * 3, P * 3, F, B * P * 3, B * F, B * F * 6]
+    packed = torch.zeros((sum(sizes),), dtype=f32, device=dev)          # render.cu:313-318 zeros_like x6
+    parts = torch.split(packed, sizes)
+    g_verts = parts[0].view(P, 3); g_color = parts[1].view(P, 3); g_opac = parts[2].view(F)
+    g_ndc = parts[3].view(B, P, 3); g_int = parts[4].view(B, F); g_aa = parts[5].view(B, F, 3, 2)
+    if F != 0 and P != 0 and num_rendered > 0 and B * H * W > 0:
+        if tuple(dL_dcolor.shape) != (B, H, W, 3) or tuple(dL_ddepth.shape) != (B, H, W):
+            raise RuntimeError("dL_dout_color / dL_dout_depth must have dimensions (B, H, W, 3) / (B, H, W)")
+        dc = _c(dL_dcolor, f32); dd = _c(dL_ddepth, f32)
+        with torch.cuda.device(dev):
+            if lib.dm2_backward(ctypes.byref(d), num_rendered, _ptr(dc), _ptr(dd), _ptr(bin_buf), bin_buf.numel(),
+                                _ptr(img_buf), img_buf.numel(), _ptr(g_verts), _ptr(g_color), _ptr(g_opac),
+                                _ptr(g_ndc), _ptr(g_int), _ptr(g_aa), _stream(dev)):
+                raise _err(lib, "render_backward_cuda")
+    g_verts._dm2_packed = packed
+    return g_verts, g_color, g_opac, g_ndc, g_int, g_aa
+
+
+def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, tet_faces, face_existence,
+                                verts_ndc, verts_image, image_ray_o, image_ray_d, num_layers):
+    """-> (render_layers (B,H,W,L) int32, -1 = empty; render_layers_cnt (B,H,W) int32)."""
+    lib = load_library()
+
+    def bad(cond, msg):
+        if cond:
+            raise RuntimeError(msg)
+    # messages of render.cu:397-429
+    bad(verts.dim() != 2 or verts.size(1) != 3, "verts must have dimensions (P, 3)")
+    bad(faces.dim() != 2 or faces.size(1) != 3, "faces must have dimensions (F, 3)")
+    bad(tets.dim() != 2 or tets.size(1) != 4, "tets must have dimensions (T, 4)")
+    bad(face_tets.dim() != 2 or face_tets.size(1) != 2, "face_tets must have dimensions (F, 2)")
+    bad(tet_faces.dim() != 2 or tet_faces.size(1) != 4, "tet_faces must have dimensions (T, 4)")
+    bad(face_existence.dim() != 1 or face_existence.size(0) != faces.size(0), "face_existence must have dimensions (F,)")
+    bad(verts_ndc.dim() != 3 or verts_ndc.size(2) != 3, "verts_ndc must have dimensions (B, P, 3)")
+    bad(verts_image.dim() != 3 or verts_image.size(2) != 2, "verts_image must have dimensions (B, P, 2)")
+    bad(image_ray_o.dim() != 4 or image_ray_o.size(3) != 3, "image_ray_o must have dimensions (B, H, W, 3)")
+    bad(image_ray_d.dim() != 4 or image_ray_d.size(3) != 3, "image_ray_d must have dimensions (B, H, W, 3)")
+    num_layers = int(num_layers); width = int(width); height = int(height)
+    bad(num_layers < 0, "num_layers must be non-negative")
+    dev = _require_gpu(verts, faces, tets, face_tets, tet_faces, face_existence, verts_ndc, verts_image, image_ray_o, image_ray_d)
+    f32, i32 = torch.float32, torch.int32
+    B, P, F, T = verts_ndc.size(0), verts.size(0), faces.size(0), tets.size(0)
+    bad(tuple(face_tets.shape) != (F, 2), "face_tets must have dimensions (F, 2)")
+    bad(tuple(tet_faces.shape) != (T, 4), "tet_faces must have dimensions (T, 4)")
+    bad(tuple(verts_ndc.shape) != (B, P, 3) or tuple(verts_image.shape) != (B, P, 2), "verts_ndc/verts_image shape mismatch")
+    bad(tuple(image_ray_o.shape) != (B, height, width, 3) or tuple(image_ray_d.shape) != (B, height, width, 3),
+        "image_ray_o/image_ray_d must have dimensions (B, H, W, 3)")
+    ts = dict(verts=_c(verts, f32), faces=_c(faces, i32), tets=_c(tets, i32), face_tets=_c(face_tets, i32),
+              tet_faces=_c(tet_faces, i32), face_existence=_c(face_existence, i32), verts_ndc=_c(verts_ndc, f32),
+              verts_image=_c(verts_image, f32), image_ray_o=_c(image_ray_o, f32), image_ray_d=_c(image_ray_d, f32))
+    d = LayersDesc()
+    d.B, d.P, d.F, d.T, d.W, d.H, d.L, d.flags = B, P, F, T, width, height, num_layers, _flags
+    for k, t in ts.items():
+        setattr(d, k, t.data_ptr() if t.numel() > 0 else None)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        cnt = torch.zeros((B, height, width), dtype=i32, device=dev)              # render.cu:437
+        layers = torch.full((B, height, width, num_layers), -1, dtype=i32, device=dev)   # render.cu:438
+        N, Tn, BF = B * height * width, _tiles(B, width, height), B * F
+        if N == 0:
+            return layers, cnt
+        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 0))
+        img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_LAYER_IMAGE, N, Tn))
+        nr = _i64(0)
+        if lib.dm2_layers_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr)):
+            raise _err(lib, "generate_render_layers_cuda (plan)")
+        R = int(nr.value)
+        bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
+        if lib.dm2_layers_run(ctypes.byref(d), R, _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
+                              _ptr(img_buf), img_buf.numel(), _ptr(layers), _ptr(cnt), st):
+            raise _err(lib, "generate_render_layers_cuda (run)")
+    generate_render_layers_cuda.last_debug = (R, face_buf, bin_buf, img_buf)      # kept for tests
+    return layers, cnt
+
+
+def debug_fetch(what, count, aux, num_rendered, scratch, dtype, n):
+    """Copy an internal array out of a scratch buffer (tests only; see dm2_debug_fetch)."""
+    lib = load_library()
+    out = torch.empty((n,), dtype=dtype, device=scratch.device)
+    if n == 0:
+        return out
+    with torch.cuda.device(scratch.device):
+        if lib.dm2_debug_fetch(what, count, aux, num_rendered, _ptr(scratch), scratch.numel(), _ptr(out), _stream(scratch.device)):
+            raise _err(lib, "debug_fetch")
+    return out

@@ -1,0 +1,208 @@
+// dm2_api.hip -- extern "C" entry points of libdm2_hip.so (include/dm2_hip.h).
+// Host orchestration equivalent to CudaRenderer::Renderer::forward/backward and
+// RenderLayerGenerator::forward (renderer.cu:78-269, 271-392, 509-674), without
+// the reference's per-stage cudaDeviceSynchronize (auxiliary.h:433-440): the
+// only host wait is the read-back of the pair count in the plan step.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "dm2_device_math.h"
+#include "dm2_state.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) { g_err = m; return 1; }
+
+#define DM2_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct PinnedWord {     // per-thread pinned staging word for the num_rendered read-back
+    uint32_t* p = nullptr;
+    ~PinnedWord() { if (p) (void)hipHostFree(p); }
+};
+thread_local PinnedWord g_pin;
+
+int read_last_offset(const uint32_t* face_offsets, int64_t BF, hipStream_t st, int64_t* out) {
+    if (BF <= 0) { *out = 0; return 0; }
+    if (!g_pin.p) DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocDefault));
+    DM2_HIP(hipMemcpyAsync(g_pin.p, face_offsets + BF - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DM2_HIP(hipStreamSynchronize(st));
+    *out = (int64_t)*g_pin.p;
+    return 0;
+}
+
+int check_render_desc(const dm2_render_desc* d) {
+    if (!d) return fail("null descriptor");
+    if (d->B < 0 || d->P < 0 || d->F < 0 || d->W < 0 || d->H < 0) return fail("negative size in descriptor");
+    if (d->aa_temperature < 0 || d->aa_temperature > 1) return fail("aa_temperature must be in the range [0, 1]");
+    if (d->K < 0) return fail("len_oarea_buffer must be non-negative");
+    const int64_t gx = (d->W + dm2::TILE - 1) / dm2::TILE, gy = (d->H + dm2::TILE - 1) / dm2::TILE;
+    if (gx > 0xFFFF || gy > 0xFFFF) return fail("patch too large: more than 65535 tiles per axis");
+    if (d->B > 65535) return fail("more than 65535 views per call");
+    if ((int64_t)d->B * gx * gy >= (1ll << 31)) return fail("too many tiles");
+    return 0;
+}
+
+inline int64_t tiles_of(int B, int W, int H) {
+    return (int64_t)B * ((W + dm2::TILE - 1) / dm2::TILE) * ((H + dm2::TILE - 1) / dm2::TILE);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dm2_abi_version(void) { return DM2_ABI_VERSION; }
+const char* dm2_last_error(void) { return g_err.c_str(); }
+
+size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
+    size_t total = 0;
+    if (count < 0) count = 0;
+    if (aux < 0) aux = 0;
+    switch (kind) {
+        case DM2_SCRATCH_FACE: dm2::FaceState::carve(nullptr, count, dm2::scan_temp_bytes(count), &total); break;
+        case DM2_SCRATCH_IMAGE: dm2::ImageState::carve(nullptr, count, aux, &total); break;
+        case DM2_SCRATCH_BINNING: dm2::BinningState::carve(nullptr, count, dm2::sort_temp_bytes(count, aux), &total); break;
+        case DM2_SCRATCH_LAYER_IMAGE: dm2::LayerImageState::carve(nullptr, count, aux, &total); break;
+        default: return 0;
+    }
+    return total;
+}
+
+int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered) {
+    if (check_render_desc(d)) return 1;
+    if (!num_rendered) return fail("num_rendered is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BF = (int64_t)d->B * d->F;
+    *num_rendered = 0;
+    if (d->P == 0 || BF == 0) return 0;                                  // render.cu:149
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+    dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, st);
+    DM2_HIP(hipGetLastError());
+    return read_last_offset(fs.face_offsets, BF, st, num_rendered);
+}
+
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_scratch, size_t face_bytes,
+                    void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream) {
+    if (check_render_desc(d)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BF = (int64_t)d->B * d->F, N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
+    if (N == 0) return 0;
+    if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
+    dm2::ImageState is = dm2::ImageState::carve(image_scratch, N, Tn);
+    const bool have_faces = (d->P != 0 && BF != 0);
+    dm2::BinningState bs{};
+    if (have_faces) {
+        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+        if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
+        dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+        bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
+        dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.depths, fs, bs, is.ranges, st);   // renderer.cu:192
+    } else {
+        DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
+    }
+    dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, st);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL_dout_color, const float* dL_dout_depth,
+                 const void* binning_scratch, size_t binning_bytes, const void* image_scratch, size_t image_bytes,
+                 float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity, float* dL_dverts_ndc,
+                 float* dL_dfaces_intense, float* dL_daa_face_verts, void* stream) {
+    if (check_render_desc(d)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
+    if (d->F == 0 || d->P == 0 || N == 0 || num_rendered <= 0) return 0;       // render.cu:320
+    if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
+    if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
+    dm2::ImageState is = dm2::ImageState::carve(const_cast<void*>(image_scratch), N, Tn);
+    dm2::BinningState bs = dm2::BinningState::carve(const_cast<void*>(binning_scratch), num_rendered,
+                                                    dm2::sort_temp_bytes(num_rendered, Tn));
+    dm2::launch_render_backward(*d, is.ranges, bs.face_list, is, dL_dout_color, dL_dout_depth, dL_dverts, dL_dverts_color,
+                                dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_layers_desc(const dm2_layers_desc* d) {
+    if (!d) return fail("null descriptor");
+    if (d->B < 0 || d->P < 0 || d->F < 0 || d->T < 0 || d->W < 0 || d->H < 0) return fail("negative size in descriptor");
+    if (d->L < 0) return fail("num_layers must be non-negative");
+    const int64_t gx = (d->W + dm2::TILE - 1) / dm2::TILE, gy = (d->H + dm2::TILE - 1) / dm2::TILE;
+    if (gx > 0xFFFF || gy > 0xFFFF || d->B > 65535) return fail("image too large");
+    if ((int64_t)d->B * gx * gy >= (1ll << 31)) return fail("too many tiles");
+    return 0;
+}
+
+int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered) {
+    if (check_layers_desc(d)) return 1;
+    if (!num_rendered) return fail("num_rendered is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BF = (int64_t)d->B * d->F;
+    *num_rendered = 0;
+    if (BF == 0) return 0;
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+    // patch_min = 0 (renderer.cu:557-558): a null patch_min means "all zeros"
+    dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, st);
+    DM2_HIP(hipGetLastError());
+    return read_last_offset(fs.face_offsets, BF, st, num_rendered);
+}
+
+int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, void* face_scratch, size_t face_bytes,
+                   void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                   int32_t* render_layers, int32_t* render_layers_cnt, void* stream) {
+    if (check_layers_desc(d)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BF = (int64_t)d->B * d->F, N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
+    if (N == 0) return 0;
+    if (dm2_scratch_bytes(DM2_SCRATCH_LAYER_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
+    dm2::LayerImageState ls = dm2::LayerImageState::carve(image_scratch, N, Tn);
+    dm2::FaceState fs{};
+    dm2::BinningState bs{};
+    if (BF != 0) {
+        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+        if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
+        fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+        bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
+        dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.min_depths, fs, bs, ls.ranges, st);   // renderer.cu:603
+    } else {
+        DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
+    }
+    dm2::launch_layers(*d, fs, ls.ranges, bs.face_list, ls, render_layers, render_layers_cnt, st);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, const void* scratch, size_t scratch_bytes,
+                    void* dst, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    (void)scratch_bytes;
+    void* base = const_cast<void*>(scratch);
+    const void* src = nullptr; size_t bytes = 0;
+    switch (what) {
+        case 0: { auto s = dm2::ImageState::carve(base, count, aux); src = s.ranges; bytes = (size_t)aux * 8; break; }
+        case 1: { auto s = dm2::BinningState::carve(base, num_rendered, dm2::sort_temp_bytes(num_rendered, aux)); src = s.face_list; bytes = (size_t)num_rendered * 4; break; }
+        case 2: { auto s = dm2::ImageState::carve(base, count, aux); src = s.final_T; bytes = (size_t)count * 4; break; }
+        case 3: { auto s = dm2::ImageState::carve(base, count, aux); src = s.final_prev_T; bytes = (size_t)count * 4; break; }
+        case 4: { auto s = dm2::ImageState::carve(base, count, aux); src = s.n_contrib; bytes = (size_t)count * 4; break; }
+        case 5: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_face; bytes = (size_t)count * 4; break; }
+        case 6: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_tet; bytes = (size_t)count * 4; break; }
+        case 7: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.ranges; bytes = (size_t)aux * 8; break; }
+        default: return fail("dm2_debug_fetch: unknown item");
+    }
+    if (bytes) DM2_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // extern "C"

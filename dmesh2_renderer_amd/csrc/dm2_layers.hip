@@ -1,0 +1,177 @@
+// dm2_layers.hip -- LayeredRenderer kernels for gfx950 (non-differentiable):
+//   k_first_intersect  firstIntersectCUDA        forward.cu:538-709
+//   k_tet_walk         generateRenderLayersCUDA  forward.cu:744-1000
+//
+// The reference's unguarded accesses are not reproduced: out-of-image lanes
+// never write first_face/first_tet (forward.cu:584-585 aliases other pixels
+// when W or H is not a multiple of 16), the "other faces" table cannot overflow
+// (forward.cu:884-896), layer writes are bounded by L, and the tet walk is
+// capped at T+1 steps so every wave terminates.
+#include <hip/hip_runtime.h>
+
+#include "dm2_device_math.h"
+#include "dm2_state.h"
+
+namespace dm2 {
+
+constexpr int LAY_CHUNK = 256;
+
+struct __attribute__((aligned(16))) LayRec {
+    float v[9];
+    float min_d, max_d;
+    int face_id;
+};
+static_assert(sizeof(LayRec) == 48, "LayRec");
+
+__device__ __forceinline__ f3 load_vert(const float* verts, int i) {
+    return {verts[3 * (int64_t)i], verts[3 * (int64_t)i + 1], verts[3 * (int64_t)i + 2]};
+}
+
+// auxiliary.h:382-431
+__device__ __forceinline__ f3 tet_face_outward_normal(const float* verts, const int32_t* faces, const int32_t* tets,
+                                                      int face_idx, int tet_idx) {
+    const f3 p0 = load_vert(verts, faces[3 * face_idx]);
+    const f3 p1 = load_vert(verts, faces[3 * face_idx + 1]);
+    const f3 p2 = load_vert(verts, faces[3 * face_idx + 2]);
+    f3 n = cross(p1 - p0, p2 - p0);
+    float n_norm = sqrtf(dot(n, n));
+    n_norm = fmaxf(n_norm, 0.0001f);
+    n = n / n_norm;
+    const f3 q0 = load_vert(verts, tets[4 * tet_idx]), q1 = load_vert(verts, tets[4 * tet_idx + 1]);
+    const f3 q2 = load_vert(verts, tets[4 * tet_idx + 2]), q3 = load_vert(verts, tets[4 * tet_idx + 3]);
+    const f3 c = (((q0 + q1) + q2) + q3) * 0.25f;
+    const f3 dd = c - p0;
+    if (dot(n, dd) > 0.0f) n = -n;
+    return n;
+}
+
+__global__ void __launch_bounds__(TILE_PIX)
+k_first_intersect(dm2_layers_desc d, const float* __restrict__ min_depths, const float* __restrict__ max_depths,
+                  const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
+                  int32_t* __restrict__ first_face, int32_t* __restrict__ first_tet) {
+    __shared__ LayRec recs[LAY_CHUNK];
+    const int b = blockIdx.z;
+    const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    const int tid = threadIdx.x;
+    const uint32_t px = blockIdx.x * TILE + (tid & 15), py = blockIdx.y * TILE + (tid >> 4);
+    const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
+    const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
+    f3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    if (inside) {
+        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
+        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+    }
+    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    bool done = !inside;
+    float min_T = -1.0f, min_T_max_depth = -1.0f;
+    int ff = -1;
+    for (int base = 0; base < total; base += LAY_CHUNK) {
+        if (__syncthreads_count(done) == TILE_PIX) break;
+        const int n = min(LAY_CHUNK, total - base);
+        if (tid < n) {
+            const int f = (int)face_list[range.x + base + tid];
+            LayRec& r = recs[tid];
+            r.face_id = f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const f3 p = load_vert(d.verts, d.faces[3 * f + i]);
+                r.v[3 * i] = p.x; r.v[3 * i + 1] = p.y; r.v[3 * i + 2] = p.z;
+            }
+            r.min_d = min_depths[(int64_t)b * d.F + f];
+            r.max_d = max_depths[(int64_t)b * d.F + f];
+        }
+        __syncthreads();
+        for (int j = 0; !done && j < n; j++) {
+            const LayRec& r = recs[j];
+            if (min_T >= 0.0f && r.min_d > min_T_max_depth) { done = true; continue; }   // forward.cu:648-651
+            f3 tuv;
+            if (!ray_tri_intersection(ro, rd, {r.v[0], r.v[1], r.v[2]}, {r.v[3], r.v[4], r.v[5]}, {r.v[6], r.v[7], r.v[8]}, tuv)) continue;
+            const bool hit = (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
+            if (!hit) continue;
+            if (min_T < 0.0f || tuv.x < min_T) { min_T = tuv.x; min_T_max_depth = r.max_d; ff = r.face_id; }
+        }
+    }
+    if (!inside) return;
+    int ft = -1;
+    if (ff >= 0) {
+        for (int i = 0; i < 2; i++) {                                   // forward.cu:689-708
+            const int tet = d.face_tets[2 * ff + i];
+            if (tet < 0) continue;
+            const f3 n = tet_face_outward_normal(d.verts, d.faces, d.tets, ff, tet);
+            if (dot(n, rd) < 0.0f) ft = tet;
+        }
+    }
+    first_face[pix] = ff;
+    first_tet[pix] = ft;
+}
+
+__global__ void __launch_bounds__(TILE_PIX)
+k_tet_walk(dm2_layers_desc d, const int32_t* __restrict__ first_face, const int32_t* __restrict__ first_tet,
+           int32_t* __restrict__ layers, int32_t* __restrict__ layers_cnt) {
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const uint32_t px = blockIdx.x * TILE + (tid & 15), py = blockIdx.y * TILE + (tid >> 4);
+    if (!((px < (uint32_t)d.W) && (py < (uint32_t)d.H))) return;
+    const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
+    const f3 ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
+    const f3 rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+    int curr_face = first_face[pix], curr_tet = first_tet[pix];
+    bool done = (curr_face == -1 || curr_tet == -1);
+    int ndone = 0, steps = 0;
+    const int L = d.L;
+    while (!done) {
+        if (++steps > d.T + 1) break;
+        if (d.face_existence[curr_face]) {                              // forward.cu:853-860
+            if (ndone < L) layers[pix * L + ndone] = curr_face;
+            ndone++;
+            if (ndone >= L) done = true;
+        }
+        if (curr_tet == -1) done = true;
+        if (done) break;
+        int others[3] = {-1, -1, -1};
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int tf = d.tet_faces[4 * curr_tet + i];
+            if (tf == curr_face) continue;
+            if (cnt == 0) others[0] = tf; else if (cnt == 1) others[1] = tf; else if (cnt == 2) others[2] = tf;
+            cnt++;
+        }
+        if (cnt != 3) break;                                            // forward.cu:892-896
+        const f3 ncur = tet_face_outward_normal(d.verts, d.faces, d.tets, curr_face, curr_tet);
+        if (dot(ncur, rd) >= 0.0f) break;                               // forward.cu:919-922
+        int next_face = -1, ncand = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int of = others[i];
+            const f3 p0 = load_vert(d.verts, d.faces[3 * of]), p1 = load_vert(d.verts, d.faces[3 * of + 1]);
+            const f3 p2 = load_vert(d.verts, d.faces[3 * of + 2]);
+            f3 tuv;
+            if (!ray_tri_intersection(ro, rd, p0, p1, p2, tuv)) continue;
+            const bool hit = (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
+            const f3 no = tet_face_outward_normal(d.verts, d.faces, d.tets, of, curr_tet);
+            if (hit && dot(no, rd) > 0.0f) { next_face = of; ncand++; }
+        }
+        if (ncand != 1) break;                                          // forward.cu:977-981
+        int next_tet = -1;
+        for (int i = 0; i < 2; i++) {
+            const int pt = d.face_tets[2 * next_face + i];
+            if (pt == curr_tet) continue;
+            next_tet = pt; break;
+        }
+        curr_face = next_face; curr_tet = next_tet;
+    }
+    layers_cnt[pix] = ndone;
+}
+
+void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,
+                   LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st) {
+    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    hipLaunchKernelGGL(k_first_intersect, grid, dim3(TILE_PIX), 0, st, d, fs.min_depths, fs.max_depths, ranges, face_list,
+                       ls.first_face, ls.first_tet);
+    hipLaunchKernelGGL(k_tet_walk, grid, dim3(TILE_PIX), 0, st, d, ls.first_face, ls.first_tet, render_layers, render_layers_cnt);
+}
+
+}  // namespace dm2

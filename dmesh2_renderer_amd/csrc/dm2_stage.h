@@ -1,0 +1,69 @@
+// dm2_stage.h -- per-list-entry face record staged in LDS by the composite kernels.
+//
+// The reference stages 96-108 B per entry in shared memory and re-reads the AA
+// tables from global memory for every (pixel,face) (forward.cu:228-243,314-317,
+// aa.h:111-120,184-203).  Here everything a (pixel,face) evaluation needs is
+// gathered ONCE per (tile,entry) into a 256-byte LDS record; the per-pixel loop
+// then reads it with wave-uniform (broadcast) ds_reads only.
+#pragma once
+#include "dm2_device_math.h"
+#include "dm2_state.h"
+
+namespace dm2 {
+
+struct __attribute__((aligned(16))) FaceRec {
+    AAFace aa;          // 32 dwords
+    float v[9];         // world-space corners
+    float col[9];       // vertex colours
+    float dep[3];       // NDC z of the corners
+    float opacity, intense;
+    int face_id;
+    int vid[3];         // vertex ids (backward scatter)
+    float pad[5];
+};
+static_assert(sizeof(FaceRec) == 256, "FaceRec must be 256 B");
+
+// Gather entry `face_id` of view `b` into `r` (one lane per record).
+__device__ __forceinline__ void stage_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
+    const int v0 = d.faces[3 * face_id], v1 = d.faces[3 * face_id + 1], v2 = d.faces[3 * face_id + 2];
+    r.face_id = face_id; r.vid[0] = v0; r.vid[1] = v1; r.vid[2] = v2;
+    const int vs[3] = {v0, v1, v2};
+    const float* ndc = d.verts_ndc + (int64_t)b * d.P * 3;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float* pv = d.verts + 3 * (int64_t)vs[i];
+        const float* pc = d.verts_color + 3 * (int64_t)vs[i];
+        r.v[3 * i] = pv[0]; r.v[3 * i + 1] = pv[1]; r.v[3 * i + 2] = pv[2];
+        r.col[3 * i] = pc[0]; r.col[3 * i + 1] = pc[1]; r.col[3 * i + 2] = pc[2];
+        r.dep[i] = ndc[3 * (int64_t)vs[i] + 2];
+    }
+    r.opacity = d.faces_opacity[face_id];
+    const int64_t bf = (int64_t)b * d.F + face_id;
+    r.intense = d.faces_intense[bf];
+    const float2* av = reinterpret_cast<const float2*>(d.aa_face_verts + bf * 6);
+    const float2* ae = reinterpret_cast<const float2*>(d.aa_face_edges + bf * 6);
+    const float2* ar = reinterpret_cast<const float2*>(d.aa_face_edges_recip + bf * 6);
+    const float2* an = reinterpret_cast<const float2*>(d.aa_face_edges_normal + bf * 6);
+    const float* ac = d.aa_face_edges_normal_c + bf * 3;
+    const uint8_t* az = d.aa_face_edges_iszero + bf * 6;
+    uint32_t zm = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float2 a = av[i], e = ae[i], rr = ar[i], n = an[i];
+        r.aa.v[2 * i] = a.x; r.aa.v[2 * i + 1] = a.y;
+        r.aa.e[2 * i] = e.x; r.aa.e[2 * i + 1] = e.y;
+        r.aa.r[2 * i] = rr.x; r.aa.r[2 * i + 1] = rr.y;
+        r.aa.n[2 * i] = n.x; r.aa.n[2 * i + 1] = n.y;
+        r.aa.c[i] = ac[i];
+        zm |= (az[2 * i] ? 1u : 0u) << (2 * i);
+        zm |= (az[2 * i + 1] ? 1u : 0u) << (2 * i + 1);
+    }
+    r.aa.zmask = zm;
+    // aa_face_verts.min(2)/.max(2)  (forward.cu:480-481, backward.cu:589-590)
+    r.aa.bb[0] = fminf(fminf(r.aa.v[0], r.aa.v[2]), r.aa.v[4]);
+    r.aa.bb[1] = fmaxf(fmaxf(r.aa.v[0], r.aa.v[2]), r.aa.v[4]);
+    r.aa.bb[2] = fminf(fminf(r.aa.v[1], r.aa.v[3]), r.aa.v[5]);
+    r.aa.bb[3] = fmaxf(fmaxf(r.aa.v[1], r.aa.v[3]), r.aa.v[5]);
+}
+
+}  // namespace dm2

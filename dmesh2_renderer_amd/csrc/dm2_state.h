@@ -1,0 +1,116 @@
+// dm2_state.h -- scratch layouts shared by the host API and the kernels.
+//
+// Same role as the reference's FaceState / ImageState / BinningState /
+// ImageRenderLayerState bump allocators (cuda_impl/state.h:10-69,
+// renderer.cu:40-76,499-507): every buffer is carved out of one caller-owned
+// byte array at 256-byte alignment, and backward re-derives the same pointers
+// from the saved arrays.  The layouts themselves are this library's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dm2_hip.h"
+
+namespace dm2 {
+
+constexpr size_t ALIGN = 256;
+
+struct Carver {
+    uintptr_t p;
+    explicit Carver(const void* base) : p(reinterpret_cast<uintptr_t>(base)) {}
+    template <class T> T* take(size_t count) {
+        p = (p + ALIGN - 1) & ~(uintptr_t)(ALIGN - 1);
+        T* r = reinterpret_cast<T*>(p);
+        p += count * sizeof(T);
+        return r;
+    }
+    size_t used(const void* base) const { return (size_t)(p - reinterpret_cast<uintptr_t>(base)); }
+};
+
+// per (batch,face): produced by the preprocess kernel
+struct FaceState {
+    float* depths;            // mean NDC z mapped to [0,1]  (sort key of Renderer)
+    float* min_depths;        // min   "                     (sort key of LayeredRenderer)
+    float* max_depths;
+    uint32_t* tiles_touched;
+    uint32_t* face_offsets;   // inclusive scan of tiles_touched
+    uint32_t* rect_lo;        // x0 | y0 << 16   (half-open tile rect, reused by the key emitter)
+    uint32_t* rect_hi;        // x1 | y1 << 16
+    void* scan_temp; size_t scan_temp_bytes;
+    static FaceState carve(void* base, int64_t BF, size_t scan_temp_bytes, size_t* total = nullptr) {
+        Carver c(base); FaceState s;
+        s.depths = c.take<float>(BF); s.min_depths = c.take<float>(BF); s.max_depths = c.take<float>(BF);
+        s.tiles_touched = c.take<uint32_t>(BF); s.face_offsets = c.take<uint32_t>(BF);
+        s.rect_lo = c.take<uint32_t>(BF); s.rect_hi = c.take<uint32_t>(BF);
+        s.scan_temp = c.take<char>(scan_temp_bytes); s.scan_temp_bytes = scan_temp_bytes;
+        if (total) *total = c.used(base) + ALIGN;
+        return s;
+    }
+};
+
+// per pixel + per tile: what backward needs from forward
+struct ImageState {
+    float* final_T;           // (N)
+    float* final_prev_T;      // (N)
+    uint32_t* n_contrib;      // (N)
+    uint2* ranges;            // (Tn) [start,end) into face_list
+    static ImageState carve(void* base, int64_t N, int64_t Tn, size_t* total = nullptr) {
+        Carver c(base); ImageState s;
+        s.final_T = c.take<float>(N); s.final_prev_T = c.take<float>(N); s.n_contrib = c.take<uint32_t>(N);
+        s.ranges = c.take<uint2>(Tn);
+        if (total) *total = c.used(base) + ALIGN;
+        return s;
+    }
+};
+
+struct LayerImageState {
+    uint2* ranges;            // (Tn)
+    int32_t* first_face;      // (N)
+    int32_t* first_tet;       // (N)
+    static LayerImageState carve(void* base, int64_t N, int64_t Tn, size_t* total = nullptr) {
+        Carver c(base); LayerImageState s;
+        s.ranges = c.take<uint2>(Tn); s.first_face = c.take<int32_t>(N); s.first_tet = c.take<int32_t>(N);
+        if (total) *total = c.used(base) + ALIGN;
+        return s;
+    }
+};
+
+struct BinningState {
+    uint32_t* face_list;          // sorted values (kept for backward)
+    uint64_t* keys;               // sorted keys
+    uint64_t* keys_unsorted;
+    uint32_t* face_list_unsorted;
+    void* sort_temp; size_t sort_temp_bytes;
+    static BinningState carve(void* base, int64_t R, size_t sort_temp_bytes, size_t* total = nullptr) {
+        Carver c(base); BinningState s;
+        s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
+        s.keys_unsorted = c.take<uint64_t>(R); s.face_list_unsorted = c.take<uint32_t>(R);
+        s.sort_temp = c.take<char>(sort_temp_bytes); s.sort_temp_bytes = sort_temp_bytes;
+        if (total) *total = c.used(base) + ALIGN;
+        return s;
+    }
+};
+
+// ---- launchers implemented in the .hip files ------------------------------------
+size_t scan_temp_bytes(int64_t BF);
+size_t sort_temp_bytes(int64_t R, int64_t Tn);
+unsigned sort_end_bit(int64_t Tn);
+
+// preprocess + inclusive scan (forward.cu:16-108, renderer.cu:165-171)
+void launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
+                            const float* verts_ndc, const float* verts_image, FaceState fs, hipStream_t st);
+// key emit + stable sort + tile ranges (renderer.cu:185-219); key depth = depths or min_depths
+void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
+                     uint2* ranges, hipStream_t st);
+
+void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                           float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
+void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                            const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
+                            float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                            float* dL_daa_face_verts, hipStream_t st);
+void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,
+                   LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
+
+}  // namespace dm2

@@ -1,0 +1,152 @@
+/* dm2_hip.h -- C ABI of libdm2_hip.so, the MI355X (gfx950) rasterizer hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's pybind module
+ * `dmesh2_renderer._C` (ext.cpp:5-9) binds, with torch types replaced by raw
+ * device pointers + sizes.  A binding (pybind/ctypes/cffi) allocates outputs
+ * and scratch with its own allocator, then calls:
+ *
+ *   render_forward_cuda        (render.h:12-45,  render.cu:28-195)
+ *       -> dm2_forward_plan() + dm2_forward_run()
+ *   render_backward_cuda       (render.h:47-94,  render.cu:198-373)
+ *       -> dm2_backward()
+ *   generate_render_layers_cuda(render.h:101-119, render.cu:378-476)
+ *       -> dm2_layers_plan() + dm2_layers_run()
+ *
+ * The plan/run split replaces the reference's resize-callback lambdas
+ * (render.cu:20-26, renderer.cu:174-183): the number of (tile,face) pairs is
+ * data dependent, so `plan` bins the faces, returns the pair count, and the
+ * caller sizes the binning scratch before `run`.
+ *
+ * All pointers are DEVICE pointers to contiguous row-major arrays unless noted.
+ * All functions enqueue on `stream` (a hipStream_t passed as void*; NULL = the
+ * null stream); only the plan functions synchronise it (one 8-byte D2H read).
+ * Return value: 0 on success, non-zero on error with a message available from
+ * dm2_last_error() (thread local).  The library keeps no global state besides
+ * a per-thread pinned staging word.
+ */
+#ifndef DM2_HIP_H
+#define DM2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM2_ABI_VERSION 1
+#define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
+
+/* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
+typedef struct dm2_render_desc {
+    int32_t B, P, F;              /* views, vertices, faces */
+    int32_t W, H;                 /* patch_width, patch_height */
+    int32_t K;                    /* len_oarea_buffer (forced to 0 when aa_temperature == 0, render.cu:141-142) */
+    float aa_temperature;         /* in [0,1] */
+    int32_t flags;                /* DM2_FLAG_* */
+    const float* background;      /* (3) */
+    const int32_t* patch_min;     /* (B,2) */
+    const float* verts;           /* (P,3) */
+    const int32_t* faces;         /* (F,3) */
+    const float* verts_color;     /* (P,3) */
+    const float* faces_opacity;   /* (F) */
+    const float* verts_ndc;       /* (B,P,3) */
+    const float* verts_image;     /* (B,P,2) */
+    const float* faces_intense;   /* (B,F) */
+    const float* aa_face_verts;             /* (B,F,3,2) */
+    const float* aa_face_edges;             /* (B,F,3,2) */
+    const uint8_t* aa_face_edges_iszero;    /* (B,F,3,2) bool */
+    const float* aa_face_edges_recip;       /* (B,F,3,2) */
+    const float* aa_face_edges_normal;      /* (B,F,3,2) */
+    const float* aa_face_edges_normal_c;    /* (B,F,3) */
+    const float* image_ray_o;     /* (B,H,W,3) */
+    const float* image_ray_d;     /* (B,H,W,3) */
+} dm2_render_desc;
+
+/* flags */
+#define DM2_FLAG_CORRECTED_DV 1  /* backward: use the true d(bary v)/d(verts) instead of the
+                                    reference's as-written d(t)/d(verts) (auxiliary.h:272-280) */
+
+/* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
+enum {
+    DM2_SCRATCH_FACE = 0,     /* count = B*F                       */
+    DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
+    DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
+    DM2_SCRATCH_LAYER_IMAGE = 3 /* count = B*H*W, aux = B*tiles    */
+};
+
+int dm2_abi_version(void);
+const char* dm2_last_error(void);
+
+/* Bytes of scratch of `kind` for `count` items (replaces required<T>(), state.h:63-69). */
+size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux);
+
+/* Bin faces into 16x16 tiles (preprocessFaceCUDA forward.cu:16-108 + InclusiveSum
+ * renderer.cu:165-171) and return the number of (tile,face) pairs
+ * (`num_rendered`, renderer.cu:174-179).  Synchronises `stream`. */
+int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
+                     void* stream, int64_t* num_rendered);
+
+/* Key emit + (tile,depth) sort + tile ranges + per-pixel composite
+ * (renderer.cu:185-266, FORWARD::renderCUDA forward.cu:139-432).
+ * out_color (B,H,W,3), out_depth (B,H,W): written for every pixel.
+ * out_tri_cnt (B,H,W) int32: number of AA records the reference would hold
+ * (min(#overlapping faces visited, K)); may be NULL.  The image/binning
+ * scratch must be kept (unmodified) for dm2_backward. */
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered,
+                    void* face_scratch, size_t face_bytes,
+                    void* binning_scratch, size_t binning_bytes,
+                    void* image_scratch, size_t image_bytes,
+                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream);
+
+/* Gradients (BACKWARD::renderCUDA backward.cu:17-532).  The six outputs must be
+ * zero-filled by the caller (the reference's zeros_like, render.cu:313-318):
+ * dL_dverts (P,3), dL_dverts_color (P,3), dL_dfaces_opacity (F),
+ * dL_dverts_ndc (B,P,3) [only z written], dL_dfaces_intense (B,F),
+ * dL_daa_face_verts (B,F,3,2). */
+int dm2_backward(const dm2_render_desc* d, int64_t num_rendered,
+                 const float* dL_dout_color, const float* dL_dout_depth,
+                 const void* binning_scratch, size_t binning_bytes,
+                 const void* image_scratch, size_t image_bytes,
+                 float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity,
+                 float* dL_dverts_ndc, float* dL_dfaces_intense, float* dL_daa_face_verts,
+                 void* stream);
+
+/* LayeredRenderer (render.h:101-119). */
+typedef struct dm2_layers_desc {
+    int32_t B, P, F, T;
+    int32_t W, H, L;              /* full frame width/height, num_layers */
+    int32_t flags;
+    const float* verts;           /* (P,3) */
+    const int32_t* faces;         /* (F,3) */
+    const int32_t* tets;          /* (T,4) */
+    const int32_t* face_tets;     /* (F,2), -1 = none */
+    const int32_t* tet_faces;     /* (T,4) */
+    const int32_t* face_existence;/* (F) */
+    const float* verts_ndc;       /* (B,P,3) */
+    const float* verts_image;     /* (B,P,2) */
+    const float* image_ray_o;     /* (B,H,W,3) */
+    const float* image_ray_d;     /* (B,H,W,3) */
+} dm2_layers_desc;
+
+int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes,
+                    void* stream, int64_t* num_rendered);
+/* render_layers (B,H,W,L) must be pre-filled with -1 and render_layers_cnt (B,H,W)
+ * with 0 by the caller (render.cu:437-438). */
+int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered,
+                   void* face_scratch, size_t face_bytes,
+                   void* binning_scratch, size_t binning_bytes,
+                   void* image_scratch, size_t image_bytes,
+                   int32_t* render_layers, int32_t* render_layers_cnt, void* stream);
+
+/* Introspection for tests/bench: copy pieces of the scratch state to caller
+ * (device) buffers.  what: 0 ranges (B*tiles*2 u32, from image scratch),
+ * 1 face_list (num_rendered u32, from binning scratch), 2 final_T, 3 final_prev_T
+ * (N f32), 4 n_contrib (N u32), 5 first_face, 6 first_tet (N i32, layer image scratch). */
+int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
+                    const void* scratch, size_t scratch_bytes, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM2_HIP_H */

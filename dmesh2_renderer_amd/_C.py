@@ -67,7 +67,22 @@ EXPORTS = {
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
     "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
+    "dm2_profile_enable": (None, [ctypes.c_int]),
+    "dm2_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
 }
+
+STAGE_NAMES = ["preprocess_scan", "emit_keys", "radix_sort", "tile_ranges", "forward_composite", "backward_composite"]
+
+
+def profile_enable(on: bool):
+    load_library().dm2_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """Per-stage milliseconds of the calling thread's most recent forward/backward (see dm2_profile_read)."""
+    buf = (ctypes.c_float * len(STAGE_NAMES))()
+    n = load_library().dm2_profile_read(buf, len(STAGE_NAMES))
+    return {STAGE_NAMES[i]: float(buf[i]) for i in range(n)}
 
 
 def load_library(path: str | None = None):

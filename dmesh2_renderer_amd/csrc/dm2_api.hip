@@ -51,13 +51,54 @@ int check_render_desc(const dm2_render_desc* d) {
     return 0;
 }
 
+struct Profiler {
+    bool on = false;
+    hipEvent_t ev[2 * DM2_PROFILE_STAGES] = {};
+    bool have[DM2_PROFILE_STAGES] = {};
+    bool created = false;
+};
+thread_local Profiler g_prof;
+
 inline int64_t tiles_of(int B, int W, int H) {
     return (int64_t)B * ((W + dm2::TILE - 1) / dm2::TILE) * ((H + dm2::TILE - 1) / dm2::TILE);
 }
 
 }  // namespace
 
+namespace dm2 {
+void prof_begin(int stage, hipStream_t st) {
+    Profiler& p = g_prof;
+    if (!p.on) return;
+    if (!p.created) { for (auto& e : p.ev) (void)hipEventCreate(&e); p.created = true; }
+    (void)hipEventRecord(p.ev[2 * stage], st);
+}
+void prof_end(int stage, hipStream_t st) {
+    Profiler& p = g_prof;
+    if (!p.on) return;
+    (void)hipEventRecord(p.ev[2 * stage + 1], st);
+    p.have[stage] = true;
+}
+}  // namespace dm2
+
 extern "C" {
+
+void dm2_profile_enable(int on) {
+    g_prof.on = on != 0;
+    for (auto& h : g_prof.have) h = false;
+}
+
+int dm2_profile_read(float* ms, int capacity) {
+    Profiler& p = g_prof;
+    int n = 0;
+    for (int s = 0; s < DM2_PROFILE_STAGES && s < capacity; s++, n++) {
+        ms[s] = 0.f;
+        if (!p.on || !p.have[s]) continue;
+        if (hipEventSynchronize(p.ev[2 * s + 1]) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.ev[2 * s], p.ev[2 * s + 1]) == hipSuccess) ms[s] = t;
+    }
+    return n;
+}
 
 int dm2_abi_version(void) { return DM2_ABI_VERSION; }
 const char* dm2_last_error(void) { return g_err.c_str(); }

@@ -118,6 +118,7 @@ void launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* pa
     if (BF == 0) return;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int blocks = (int)((BF + 255) / 256);
+    StageTimer tm(ST_PREP, st);
     hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs);
     size_t bytes = fs.scan_temp_bytes;
     (void)rocprim::inclusive_scan(fs.scan_temp, bytes, fs.tiles_touched, fs.face_offsets, (size_t)BF, rocprim::plus<uint32_t>(), st);
@@ -130,11 +131,18 @@ void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_dep
     (void)hipMemsetAsync(ranges, 0, (size_t)Tn * sizeof(uint2), st);           // renderer.cu:211
     if (R <= 0) return;
     const int64_t BF = (int64_t)B * F;
-    hipLaunchKernelGGL(k_emit_keys, dim3((int)((BF + 255) / 256)), dim3(256), 0, st, B, F, gx, gy, key_depth, fs,
-                       bs.keys_unsorted, bs.face_list_unsorted);
-    size_t bytes = bs.sort_temp_bytes;
-    (void)rocprim::radix_sort_pairs(bs.sort_temp, bytes, bs.keys_unsorted, bs.keys, bs.face_list_unsorted, bs.face_list,
-                                    (size_t)R, 0u, sort_end_bit(Tn), st);
+    {
+        StageTimer tm(ST_EMIT, st);
+        hipLaunchKernelGGL(k_emit_keys, dim3((int)((BF + 255) / 256)), dim3(256), 0, st, B, F, gx, gy, key_depth, fs,
+                           bs.keys_unsorted, bs.face_list_unsorted);
+    }
+    {
+        StageTimer tm(ST_SORT, st);
+        size_t bytes = bs.sort_temp_bytes;
+        (void)rocprim::radix_sort_pairs(bs.sort_temp, bytes, bs.keys_unsorted, bs.keys, bs.face_list_unsorted, bs.face_list,
+                                        (size_t)R, 0u, sort_end_bit(Tn), st);
+    }
+    StageTimer tm(ST_RANGES, st);
     hipLaunchKernelGGL(k_tile_ranges, dim3((int)((R + 255) / 256)), dim3(256), 0, st, R, bs.keys, ranges);
 }
 

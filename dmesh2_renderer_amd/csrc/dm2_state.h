@@ -114,3 +114,15 @@ void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* r
                    LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
 
 }  // namespace dm2
+
+// ---- optional per-stage hipEvent timing (dm2_profile_enable; defined in dm2_api.hip) ----
+namespace dm2 {
+enum Stage { ST_PREP = 0, ST_EMIT = 1, ST_SORT = 2, ST_RANGES = 3, ST_FWD = 4, ST_BWD = 5 };
+void prof_begin(int stage, hipStream_t st);
+void prof_end(int stage, hipStream_t st);
+struct StageTimer {
+    int s; hipStream_t st;
+    StageTimer(int stage, hipStream_t stream) : s(stage), st(stream) { prof_begin(s, st); }
+    ~StageTimer() { prof_end(s, st); }
+};
+}  // namespace dm2

@@ -105,10 +105,17 @@ def triangle_soup(width: int, height: int, num_faces: int, seed: int,
     zw = -depth + CAM_DIST
     verts = torch.stack([xv, yv, zw], dim=-1).reshape(F * 3, 3).to(torch.float32)
     faces = torch.arange(F * 3, dtype=torch.int32).reshape(F, 3)
-    if shared_verts and F >= 4:
-        # weld: every 4th face reuses vertex 0 of the previous face
+    if shared_verts and F >= 2:
+        # weld pairs into quads: odd face f shares the edge (v1,v0) of face f-1 and
+        # gets its third corner mirrored across that edge, so vertex rows are
+        # shared between faces (gradient scatter collides) without giant triangles
         faces = faces.clone()
-        faces[3::4, 0] = faces[2::4, 0][: faces[3::4, 0].shape[0]]
+        odd = torch.arange(1, F, 2)
+        v3 = verts.reshape(F, 3, 3)
+        v3[odd, 2] = v3[odd - 1, 0] + v3[odd - 1, 1] - v3[odd - 1, 2]
+        verts = v3.reshape(F * 3, 3).contiguous()
+        faces[odd, 0] = faces[odd - 1, 1]
+        faces[odd, 1] = faces[odd - 1, 0]
     P = verts.shape[0]
     verts_color = torch.rand((P, 3), generator=g, dtype=torch.float32)
     faces_opacity = (torch.rand((F,), generator=g, dtype=torch.float32) * 0.7 + 0.2)

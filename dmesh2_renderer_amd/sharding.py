@@ -1,0 +1,113 @@
+"""Tile-row band sharding of one frame across the GPUs of a node.
+
+The reference is single-GPU, but its op already renders arbitrary
+sub-rectangles through ``patch_min / patch_width / patch_height``
+(render.h:17-19, auxiliary.h:72-92).  Per-pixel results depend only on the
+faces overlapping that pixel, so GPU ``g`` of ``G`` renders tile rows
+``[floor(g*Ty/G), floor((g+1)*Ty/G))`` as one band-shaped patch; band edges sit
+on multiples of 16 so every band's tile grid coincides with the single-GPU one
+and the band images are bit-identical to the corresponding rows of the full
+frame.  Geometry is replicated.  The forward needs no exchange; the backward
+produces a full-size partial gradient on every rank, packed in ONE fp32 buffer
+(see ``_C.render_backward_cuda``), summed with ONE all-reduce (RCCL over xGMI
+when the process group's backend is ``nccl``; ``gloo`` in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+TILE = 16
+
+
+def band_rows(height: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """(first pixel row, number of pixel rows) of rank's band; may be (y0, 0) for surplus ranks."""
+    ty = (height + TILE - 1) // TILE
+    t0 = (rank * ty) // world_size
+    t1 = ((rank + 1) * ty) // world_size
+    y0 = min(t0 * TILE, height)
+    y1 = min(t1 * TILE, height)
+    return y0, y1 - y0
+
+
+def all_bands(height: int, world_size: int) -> List[Tuple[int, int]]:
+    return [band_rows(height, world_size, r) for r in range(world_size)]
+
+
+def allreduce_packed_grads(grads, group=None):
+    """Sum the six gradient tensors over ranks with a single collective.
+
+    ``grads`` is the 6-tuple of ``_C.render_backward_cuda``; its tensors are
+    views of one packed buffer (``grads[0]._dm2_packed``), which is reduced in
+    place.  Falls back to flatten/unflatten for foreign tensors.
+    """
+    import torch.distributed as dist
+    packed = getattr(grads[0], "_dm2_packed", None)
+    if packed is not None:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        return grads
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, off = [], 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g)); off += n
+        out.append(g)
+    return tuple(out)
+
+
+class BandShardedOp:
+    """Forward/backward of the render op on this rank's band of a full-frame call.
+
+    ``full_args`` are the 21 boundary arguments of a FULL-frame call
+    (patch_min = (0,0), patch = whole image, B arbitrary); the band's arguments
+    are derived by slicing the ray tensors and moving ``patch_min``.
+    """
+
+    def __init__(self, full_args, world_size: int, rank: int, backend=None):
+        from . import _C
+        self._C = backend or _C
+        self.world_size, self.rank = world_size, rank
+        a = list(full_args)
+        H = int(a[3])
+        self.y0, self.rows = band_rows(H, world_size, rank)
+        pm = a[1].clone()
+        pm[:, 1] += self.y0
+        a[1] = pm
+        a[3] = self.rows
+        a[19] = a[19][:, self.y0:self.y0 + self.rows].contiguous()
+        a[20] = a[20][:, self.y0:self.y0 + self.rows].contiguous()
+        self.args = a
+        self.fwd = None
+
+    def forward(self):
+        """-> (color, depth) of this rank's band: rows [y0, y0+rows) of the frame."""
+        if self.rows == 0:
+            a = self.args
+            B, W = a[8].shape[0], int(a[2])
+            dev = a[8].device
+            self.fwd = None
+            return torch.zeros((B, 0, W, 3), device=dev), torch.zeros((B, 0, W), device=dev)
+        self.fwd = self._C.render_forward_cuda(*self.args)
+        return self.fwd[1], self.fwd[2]
+
+    def backward(self, dL_dcolor_band, dL_ddepth_band, group=None, reduce=True):
+        """Band gradients -> full gradients (summed over ranks when ``reduce``)."""
+        a = self.args
+        if self.rows == 0:
+            P, F, B = a[4].shape[0], a[5].shape[0], a[8].shape[0]
+            dev = a[4].device
+            sizes = [P * 3, P * 3, F, B * P * 3, B * F, B * F * 6]
+            packed = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
+            parts = torch.split(packed, sizes)
+            grads = (parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(F), parts[3].view(B, P, 3),
+                     parts[4].view(B, F), parts[5].view(B, F, 3, 2))
+            grads[0]._dm2_packed = packed
+        else:
+            f = self.fwd
+            grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
+                                                 f[3], f[4], f[5], f[6])
+        if reduce and self.world_size > 1:
+            grads = allreduce_packed_grads(grads, group)
+        return grads

@@ -146,6 +146,16 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered,
 int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
                     const void* scratch, size_t scratch_bytes, void* dst, void* stream);
 
+/* Optional per-stage timing (bench/profiling only; off by default).  When enabled, the
+ * forward/backward/layers entry points record hipEvents on `stream` around every stage of
+ * the calling thread's next calls; dm2_profile_read waits for the last one and returns the
+ * milliseconds of each stage of the most recent forward_plan/forward_run/backward call:
+ * [0] preprocess+scan  [1] key emit  [2] radix sort  [3] tile ranges
+ * [4] forward composite [5] backward composite.  Returns the number of values written. */
+#define DM2_PROFILE_STAGES 6
+void dm2_profile_enable(int on);
+int dm2_profile_read(float* ms, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ import torch
 
 SEED_BASE = 20250224  # manual_seed(20250224 + cfg)
 TAN_HALF_FOV = 0.5
-Z_NEAR = 0.1
+Z_NEAR = 1.0   # the reference builds ray targets from NDC (x,y,-1,1) WITHOUT a perspective divide (__init__.py:225-231): that is a true pixel ray only when the near plane sits at distance 1 (inv(proj) then returns w=1). SURVEY 8d suggested 0.1, which makes every ray point away from the scene.
 Z_FAR = 10.0
 CAM_DIST = 3.0
 

@@ -27,6 +27,7 @@ _lib = None
 _lock = threading.Lock()
 
 DM2_FLAG_CORRECTED_DV = 1
+DM2_FLAG_LEGACY_KERNELS = 2
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE = 0, 1, 2, 3
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)

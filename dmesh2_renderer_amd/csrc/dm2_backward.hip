@@ -225,6 +225,11 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                             float* dL_daa_face_verts, hipStream_t st) {
+    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
+        launch_render_backward_dense(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                     dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
+        return;
+    }
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,

@@ -1,0 +1,297 @@
+// dm2_backward_dense.hip -- backward composite, dense (pixel,face)-pair formulation.
+//
+// Same results as k_render_backward (dm2_backward.hip; BACKWARD::renderCUDA<3>,
+// backward.cu:17-532) up to fp32 summation order of the scattered gradients.
+// Per chunk of staged faces (walked back to front) and per batch of 256 pairs:
+//   B  lane k: recompute AA area + Jacobian, Moeller-Trumbore, clamp, coverage,
+//      alpha, interpolated colour/depth of pair k  -> small record in LDS;
+//      the Jacobian / barycentrics stay in registers.
+//   C  pixel p: replay its pairs of the batch back to front (transmittance
+//      recovery, dL/dalpha recurrence, backward.cu:340-405) -> T, dL/dalpha into the record.
+//   D  lane k: chain rule for pair k (backward.cu:408-488) and 29 ds_add_f32 into the
+//      per-(tile,entry) accumulators; flushed per chunk with (entry,component) atomics.
+#include <hip/hip_runtime.h>
+
+#include "dm2_device_math.h"
+#include "dm2_pairs.h"
+#include "dm2_stage.h"
+#include "dm2_state.h"
+
+namespace dm2 {
+
+constexpr int BD_CHUNK = 128;
+constexpr int BD_ACC = 32;
+constexpr int B_DV = 0, B_DC = 9, B_DZ = 18, B_OP = 21, B_IN = 22, B_AA = 23, B_N = 29, B_FLAG = 31;
+constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
+
+struct __attribute__((aligned(16))) BwdPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
+static_assert(sizeof(BwdPair) == 32, "BwdPair");
+
+__global__ void __launch_bounds__(TILE_PIX)
+k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
+                        ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                        float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
+                        float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
+                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts) {
+    __shared__ FaceRec recs[BD_CHUNK];
+    __shared__ float acc[BD_CHUNK * BD_ACC];
+    __shared__ BwdPair s_pair[2][TILE_PIX];
+    __shared__ float s_ray[TILE_PIX * 6];
+    __shared__ float s_dL[TILE_PIX * 4];
+    __shared__ int s_off[BD_CHUNK + 1];
+    __shared__ uint32_t s_rect[BD_CHUNK];
+    __shared__ int s_wave[4];
+    __shared__ uint32_t s_max_lc;
+
+    const int b = blockIdx.z;
+    const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    const int tid = threadIdx.x;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const uint32_t px = X0 + lx, py = Y0 + ly;
+    const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
+    const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
+    const uint32_t pmx = (uint32_t)d.patch_min[2 * b], pmy = (uint32_t)d.patch_min[2 * b + 1];
+    const int X0a = X0 + (int)pmx, Y0a = Y0 + (int)pmy;
+    const int xlim = min(TILE - 1, d.W - 1 - X0), ylim = min(TILE - 1, d.H - 1 - Y0);
+    const bool corrected = (d.flags & DM2_FLAG_CORRECTED_DV) != 0;
+
+    float T_final = 0.f, prev_T_final = 0.f;
+    uint32_t last_contributor = 0;
+    float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f;
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s_ray[tid * 6 + k] = d.image_ray_o[3 * pix + k];
+            s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
+        }
+        T_final = is.final_T[pix]; prev_T_final = is.final_prev_T[pix];
+        last_contributor = is.n_contrib[pix];
+        dLc0 = dL_dcolor[3 * pix]; dLc1 = dL_dcolor[3 * pix + 1]; dLc2 = dL_dcolor[3 * pix + 2];
+        dLd = dL_ddepth[pix];
+        s_dL[tid * 4] = dLc0; s_dL[tid * 4 + 1] = dLc1; s_dL[tid * 4 + 2] = dLc2; s_dL[tid * 4 + 3] = dLd;
+    }
+    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
+    const uint2 range = ranges[tile];
+
+    if (tid == 0) s_max_lc = 0;
+    __syncthreads();
+    if (last_contributor) atomicMax(&s_max_lc, last_contributor);
+    __syncthreads();
+    const int total = (int)min(s_max_lc, range.y - range.x);       // entries behind every pixel's last contributor are dead
+
+    const float temp = d.aa_temperature;
+    const bool use_aa = temp > 0.0f;
+    const float pix_area = 1.0f;
+    const float bg0 = d.background[0], bg1 = d.background[1], bg2 = d.background[2];
+
+    float T = prev_T_final;
+    bool T_first_pass = true;
+    float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_recd = 0.f;
+    float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
+
+    for (int base = 0; base < total; base += BD_CHUNK) {
+        __syncthreads();                                            // previous chunk flushed, LDS reusable
+        const int n = min(BD_CHUNK, total - base);
+        int cnt = 0;
+        if (tid < n) {
+            // recs[j] = entry (total-1) - (base+j): back to front (backward.cu:171)
+            stage_face(d, b, (int)face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
+            uint32_t rect;
+            cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
+            s_rect[tid] = rect;
+        }
+        for (int k = tid; k < n * BD_ACC; k += TILE_PIX) acc[k] = 0.f;
+        int tot;
+        const int ex = block_exclusive_scan(cnt, s_wave, tot);
+        if (tid < n) s_off[tid] = ex;
+        if (tid == n) s_off[n] = tot;
+        __syncthreads();
+        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+
+        for (int bi = 0; bi < nb; bi++) {
+            // ---- phase B ------------------------------------------------------------------
+            const int k = bi * TILE_PIX + tid;
+            const bool have = k < tot;
+            int j = 0, q = 0;
+            float dg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float i0 = 0.f, i1 = 0.f, i2 = 0.f, ratio = 0.f, alpha = 0.f;
+            int code = 0;
+            bool blend = false;
+            if (have) {
+                j = find_face(s_off, n, k);
+                const uint32_t rect = s_rect[j];
+                int qx, qy;
+                pair_xy(rect, k - s_off[j], qx, qy);
+                q = qy * TILE + qx;
+                const FaceRec& fc = recs[j];
+                const float pxmin = (float)(uint32_t)(X0a + qx), pxmax = pxmin + 1;
+                const float pymin = (float)(uint32_t)(Y0a + qy), pymax = pymin + 1;
+                float oarea = 0.f;
+                bool live = true;
+                if (use_aa) {
+                    const int err = tri_pix_overlap_area<true>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, dg);
+                    live = !((err != 0) || (oarea == 0.0f));
+                }
+                BwdPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
+                if (live) {
+                    ratio = oarea / pix_area;
+                    const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
+                    const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
+                    const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                    f3 tuv = {0, 0, 0};
+                    if (ray_tri_intersection(ro, rd, p0, p1, p2, tuv)) {
+                        float iuc, ivc;
+                        clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
+                        i0 = 1 - iuc - ivc; i1 = iuc; i2 = ivc;
+                        ratio = mix_coverage(code, ratio, temp);
+                        if (ratio != 0.0f) {
+                            float c0 = i0 * fc.col[0] + i1 * fc.col[3] + i2 * fc.col[6];
+                            float c1 = i0 * fc.col[1] + i1 * fc.col[4] + i2 * fc.col[7];
+                            float c2 = i0 * fc.col[2] + i1 * fc.col[5] + i2 * fc.col[8];
+                            out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
+                            out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
+                            alpha = fc.opacity * ratio;
+                            out.alpha = alpha;
+                            out.flags = BF_BLEND;
+                            blend = true;
+                        }
+                    }
+                }
+                s_pair[bi & 1][tid] = out;
+            }
+            __syncthreads();
+
+            // ---- phase C: per-pixel back-to-front replay ------------------------------------
+            if (inside) {
+                const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
+                const int jlo = find_face(s_off, n, k0), jhi = find_face(s_off, n, k1 - 1);
+                for (int jj = jlo; jj <= jhi; jj++) {
+                    const uint32_t e = (uint32_t)(total - 1 - base - jj);        // 0-based position in the list
+                    if (e >= last_contributor) continue;                          // backward.cu:219-221
+                    const int o = s_off[jj];
+                    if (s_off[jj + 1] == o) continue;
+                    const int kk = pixel_pair(s_rect[jj], o, lx, ly);
+                    if (kk < k0 || kk >= k1) continue;
+                    BwdPair& pr = s_pair[bi & 1][kk - k0];
+                    if (!(pr.flags & BF_BLEND)) continue;
+                    const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
+                    if (!T_first_pass) T = T / (1.f - a);                         // backward.cu:340-348
+                    T_first_pass = false;
+                    float dL_dalpha = 0.0f;
+                    accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = iC0;
+                    dL_dalpha += (iC0 - accum_rec0) * dLc0;
+                    accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1; last_c1 = iC1;
+                    dL_dalpha += (iC1 - accum_rec1) * dLc1;
+                    accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2; last_c2 = iC2;
+                    dL_dalpha += (iC2 - accum_rec2) * dLc2;
+                    accum_recd = last_alpha * last_depth + (1.f - last_alpha) * accum_recd; last_depth = iD;
+                    dL_dalpha += (iD - accum_recd) * dLd;
+                    dL_dalpha *= T;
+                    last_alpha = a;
+                    float bg_dot = 0.f;
+                    bg_dot += bg0 * dLc0; bg_dot += bg1 * dLc1; bg_dot += bg2 * dLc2;
+                    const float bd_dot = (float)(0.0 + 1.0 * (double)dLd);        // backward.cu:394
+                    if (a == 1.0f) {
+                        dL_dalpha += (-prev_T_final) * bg_dot;
+                        dL_dalpha += (-prev_T_final) * bd_dot;
+                    } else {
+                        dL_dalpha += (-T_final / (1.f - a)) * bg_dot;
+                        dL_dalpha += (-T_final / (1.f - a)) * bd_dot;
+                    }
+                    pr.T = T; pr.dL_dalpha = dL_dalpha; pr.flags = BF_BLEND | BF_ACTIVE;
+                }
+            }
+            __syncthreads();
+
+            // ---- phase D: chain rule + per-entry accumulation -------------------------------
+            if (have && blend) {
+                const BwdPair pr = s_pair[bi & 1][tid];
+                if (pr.flags & BF_ACTIVE) {
+                    const FaceRec& fc = recs[j];
+                    const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
+                    const float qc0 = s_dL[q * 4], qc1 = s_dL[q * 4 + 1], qc2 = s_dL[q * 4 + 2], qd = s_dL[q * 4 + 3];
+                    const float intense = fc.intense, opacity = fc.opacity;
+                    const float dics[3] = {qc0 * alpha * Tq, qc1 * alpha * Tq, qc2 * alpha * Tq};
+                    const float did = qd * alpha * Tq;
+                    const float dL_dfop = dL_dalpha * ratio;
+                    const float dL_dratio = (dL_dalpha * opacity) * temp;
+                    const float dL_doarea = dL_dratio / pix_area;
+                    float dL_di0 = 0.f, dL_di1 = 0.f, dL_di2 = 0.f, dL_dfint = 0.f;
+                    float dvc[9];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dL_di0 += fc.col[ch] * dics[ch] * intense;
+                        dL_di1 += fc.col[3 + ch] * dics[ch] * intense;
+                        dL_di2 += fc.col[6 + ch] * dics[ch] * intense;
+                        dvc[ch] = 0.f + i0 * dics[ch] * intense;
+                        dvc[3 + ch] = 0.f + i1 * dics[ch] * intense;
+                        dvc[6 + ch] = 0.f + i2 * dics[ch] * intense;
+                        dL_dfint += (i0 * fc.col[ch] + i1 * fc.col[3 + ch] + i2 * fc.col[6 + ch]) * dics[ch];
+                    }
+                    dL_di0 += fc.dep[0] * did; dL_di1 += fc.dep[1] * did; dL_di2 += fc.dep[2] * did;
+                    const float dvd0 = 0.f + i0 * did, dvd1 = 0.f + i1 * did, dvd2 = 0.f + i2 * did;
+                    float diuc_diu, diuc_div, divc_diu, divc_div;
+                    clamp_bary_uv_grad(code, diuc_diu, diuc_div, divc_diu, divc_div);
+                    const float di0_diu = -1.f * diuc_diu + -1.f * divc_diu, di0_div = -1.f * diuc_div + -1.f * divc_div;
+                    const float di1_diu = 1.f * diuc_diu + 0.f * divc_diu, di1_div = 1.f * diuc_div + 0.f * divc_div;
+                    const float di2_diu = 0.f * diuc_diu + 1.f * divc_diu, di2_div = 0.f * diuc_div + 1.f * divc_div;
+                    const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
+                    const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+                    const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
+                    const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
+                    const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                    f3 du0, du1, du2, dv0, dv1, dv2;
+                    ray_tri_intersection_grad(ro, rd, p0, p1, p2, corrected, du0, du1, du2, dv0, dv1, dv2);
+                    const f3 dp0 = dL_diu * du0 + dL_div * dv0;
+                    const f3 dp1 = dL_diu * du1 + dL_div * dv1;
+                    const f3 dp2 = dL_diu * du2 + dL_div * dv2;
+                    float* a = acc + j * BD_ACC;
+                    atomicAdd(a + B_DV + 0, dp0.x); atomicAdd(a + B_DV + 1, dp0.y); atomicAdd(a + B_DV + 2, dp0.z);
+                    atomicAdd(a + B_DV + 3, dp1.x); atomicAdd(a + B_DV + 4, dp1.y); atomicAdd(a + B_DV + 5, dp1.z);
+                    atomicAdd(a + B_DV + 6, dp2.x); atomicAdd(a + B_DV + 7, dp2.y); atomicAdd(a + B_DV + 8, dp2.z);
+#pragma unroll
+                    for (int c = 0; c < 9; c++) atomicAdd(a + B_DC + c, dvc[c]);
+                    atomicAdd(a + B_DZ + 0, dvd0); atomicAdd(a + B_DZ + 1, dvd1); atomicAdd(a + B_DZ + 2, dvd2);
+                    atomicAdd(a + B_OP, dL_dfop);
+                    atomicAdd(a + B_IN, dL_dfint);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) atomicAdd(a + B_AA + c, dL_doarea * dg[c]);
+                    a[B_FLAG] = 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- flush: lane = (entry, component); 8 entries per pass --------------------------
+        const int comp = tid & 31;
+        if (comp < B_N) {
+            for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
+                const float* a = acc + e * BD_ACC;
+                if (a[B_FLAG] == 0.f) continue;
+                const FaceRec& fc = recs[e];
+                const float val = a[comp];
+                float* dst;
+                if (comp < B_DC) dst = dL_dverts + 3 * (int64_t)fc.vid[comp / 3] + (comp % 3);
+                else if (comp < B_DZ) dst = dL_dverts_color + 3 * (int64_t)fc.vid[(comp - B_DC) / 3] + ((comp - B_DC) % 3);
+                else if (comp < B_OP) dst = dL_dverts_ndc + ((int64_t)b * d.P + fc.vid[comp - B_DZ]) * 3 + 2;
+                else if (comp == B_OP) dst = dL_dfaces_opacity + fc.face_id;
+                else if (comp == B_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
+                else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - B_AA);
+                atomicAdd(dst, val);
+            }
+        }
+    }
+}
+
+void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
+                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                                  float* dL_daa_face_verts, hipStream_t st) {
+    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    StageTimer tm(ST_BWD, st);
+    hipLaunchKernelGGL(k_render_backward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts);
+}
+
+}  // namespace dm2

@@ -1,0 +1,177 @@
+// dm2_forward_dense.hip -- forward composite, dense (pixel,face)-pair formulation.
+//
+// Same results as k_render_forward (dm2_forward.hip; FORWARD::renderCUDA<3>,
+// forward.cu:139-432), different work distribution (see dm2_pairs.h): per chunk of
+// staged faces, phase B evaluates the expensive per-pair quantities (AA overlap
+// area, Moeller-Trumbore, barycentric clamp, coverage mix, interpolated colour /
+// depth) with one pair per lane, phase C lets every pixel blend its own pairs in
+// list order.  One barrier per batch of 256 pairs (pair records double buffered).
+#include <hip/hip_runtime.h>
+
+#include "dm2_device_math.h"
+#include "dm2_pairs.h"
+#include "dm2_stage.h"
+#include "dm2_state.h"
+
+namespace dm2 {
+
+constexpr int FD_CHUNK = 128;
+constexpr uint32_t PF_REC = 1u;      // AA overlap found (the reference takes an AA record here)
+constexpr uint32_t PF_BLEND = 2u;    // the face blends into the pixel
+
+struct __attribute__((aligned(8))) FwdPair { float alpha, c0, c1, c2, depth; uint32_t flags; };
+
+__global__ void __launch_bounds__(TILE_PIX)
+k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
+                       ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
+                       int32_t* __restrict__ out_tri_cnt) {
+    __shared__ FaceRec recs[FD_CHUNK];
+    __shared__ FwdPair s_pair[2][TILE_PIX];
+    __shared__ float s_ray[TILE_PIX * 6];
+    __shared__ int s_off[FD_CHUNK + 1];
+    __shared__ uint32_t s_rect[FD_CHUNK];
+    __shared__ int s_wave[4];
+
+    const int b = blockIdx.z;
+    const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    const int tid = threadIdx.x;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const uint32_t px = X0 + lx, py = Y0 + ly;
+    const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
+    const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
+    const uint32_t pmx = (uint32_t)d.patch_min[2 * b], pmy = (uint32_t)d.patch_min[2 * b + 1];
+    const int X0a = X0 + (int)pmx, Y0a = Y0 + (int)pmy;
+    const int xlim = min(TILE - 1, d.W - 1 - X0), ylim = min(TILE - 1, d.H - 1 - Y0);
+
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s_ray[tid * 6 + k] = d.image_ray_o[3 * pix + k];
+            s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
+        }
+    }
+    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const float temp = d.aa_temperature;
+    const bool use_aa = temp > 0.0f;
+    const float pix_area = 1.0f;
+    const int K = d.K;
+
+    bool done = !inside;
+    float pT = 1.0f, T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    int rec_cnt = 0;
+
+    for (int base = 0; base < total; base += FD_CHUNK) {
+        if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260; also fences LDS reuse
+        const int n = min(FD_CHUNK, total - base);
+        int cnt = 0;
+        if (tid < n) {
+            stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
+            uint32_t rect;
+            cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
+            s_rect[tid] = rect;
+        }
+        int tot;
+        const int ex = block_exclusive_scan(cnt, s_wave, tot);
+        if (tid < n) s_off[tid] = ex;
+        if (tid == n) s_off[n] = tot;
+        __syncthreads();
+        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+
+        // ---- phase B: one pair per lane ------------------------------------------------
+        auto eval_batch = [&](int bi) {
+            const int k = bi * TILE_PIX + tid;
+            if (k >= tot) return;
+            const int j = find_face(s_off, n, k);
+            const uint32_t rect = s_rect[j];
+            int qx, qy;
+            pair_xy(rect, k - s_off[j], qx, qy);
+            const int q = qy * TILE + qx;
+            const FaceRec& fc = recs[j];
+            const float pxmin = (float)(uint32_t)(X0a + qx), pxmax = pxmin + 1;
+            const float pymin = (float)(uint32_t)(Y0a + qy), pymax = pymin + 1;
+            FwdPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0;
+            float oarea = 0.f;
+            bool live = true;
+            if (use_aa) {
+                const int err = tri_pix_overlap_area<false>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, nullptr);
+                live = !((err != 0) || (oarea == 0.0f));
+                if (live) out.flags |= PF_REC;
+            }
+            if (live) {
+                float ratio = oarea / pix_area;
+                const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
+                const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
+                const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                f3 tuv = {0, 0, 0};
+                if (ray_tri_intersection(ro, rd, p0, p1, p2, tuv)) {
+                    float iuc, ivc; int code;
+                    clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
+                    const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+                    ratio = mix_coverage(code, ratio, temp);
+                    if (ratio != 0.0f) {
+                        float c0 = i0 * fc.col[0] + i1 * fc.col[3] + i2 * fc.col[6];
+                        float c1 = i0 * fc.col[1] + i1 * fc.col[4] + i2 * fc.col[7];
+                        float c2 = i0 * fc.col[2] + i1 * fc.col[5] + i2 * fc.col[8];
+                        out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
+                        out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
+                        out.alpha = fc.opacity * ratio;
+                        out.flags |= PF_BLEND;
+                    }
+                }
+            }
+            s_pair[bi & 1][tid] = out;
+        };
+
+        if (nb > 0) eval_batch(0);
+        for (int bi = 0; bi < nb; bi++) {
+            __syncthreads();
+            // ---- phase C: ordered blend of this pixel's pairs of batch bi ---------------
+            if (!done) {
+                const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
+                const int jlo = find_face(s_off, n, k0), jhi = find_face(s_off, n, k1 - 1);
+                for (int j = jlo; j <= jhi; j++) {
+                    const int o = s_off[j];
+                    if (s_off[j + 1] == o) continue;
+                    const int k = pixel_pair(s_rect[j], o, lx, ly);
+                    if (k < k0 || k >= k1) continue;
+                    const FwdPair pr = s_pair[bi & 1][k - k0];
+                    if ((pr.flags & PF_REC) && rec_cnt < K) rec_cnt++;       // forward.cu:344-352
+                    if (!(pr.flags & PF_BLEND)) continue;
+                    const float alpha = pr.alpha;
+                    const float test_T = T * (1 - alpha);
+                    C0 += pr.c0 * alpha * T; C1 += pr.c1 * alpha * T; C2 += pr.c2 * alpha * T;
+                    D += pr.depth * alpha * T;
+                    pT = T; T = test_T;
+                    last_contributor = (uint32_t)(base + j + 1);
+                    if (T < T_EPS) { done = true; break; }
+                }
+            }
+            if (bi + 1 < nb) eval_batch(bi + 1);
+        }
+    }
+
+    if (inside) {
+        is.final_prev_T[pix] = pT;
+        is.final_T[pix] = T;
+        is.n_contrib[pix] = last_contributor;
+        out_color[3 * pix] = C0 + T * d.background[0];
+        out_color[3 * pix + 1] = C1 + T * d.background[1];
+        out_color[3 * pix + 2] = C2 + T * d.background[2];
+        out_depth[pix] = D + T * 1.0f;
+        if (out_tri_cnt) out_tri_cnt[pix] = rec_cnt;
+    }
+}
+
+void launch_render_forward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
+    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    StageTimer tm(ST_FWD, st);
+    hipLaunchKernelGGL(k_render_forward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt);
+}
+
+}  // namespace dm2

@@ -67,6 +67,9 @@ typedef struct dm2_render_desc {
 #define DM2_FLAG_CORRECTED_DV 1  /* backward: use the true d(bary v)/d(verts) instead of the
                                     reference's as-written d(t)/d(verts) (auxiliary.h:272-280) */
 
+#define DM2_FLAG_LEGACY_KERNELS 2 /* composite kernels: per-pixel list walk (reference-shaped work distribution)
+                                    instead of the dense (pixel,face)-pair kernels; same results, kept for A/B */
+
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F                       */

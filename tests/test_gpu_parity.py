@@ -22,6 +22,15 @@ def _C():
     return c
 
 
+@pytest.fixture(autouse=True, params=["dense", "legacy"])
+def kernels(request):
+    """Every test runs against both work distributions of the composite kernels (same results required)."""
+    c = _C()
+    old = c.set_flags(c.DM2_FLAG_LEGACY_KERNELS if request.param == "legacy" else 0)
+    yield request.param
+    c.set_flags(old)
+
+
 def _orc():
     from oracle import cpu as orc
     return orc

@@ -70,6 +70,7 @@ EXPORTS = {
     "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
     "dm2_profile_enable": (None, [ctypes.c_int]),
     "dm2_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
+    "dm2_debug_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]),
 }
 
 STAGE_NAMES = ["preprocess_scan", "emit_keys", "radix_sort", "tile_ranges", "forward_composite", "backward_composite"]

@@ -10,7 +10,18 @@
 #include <string>
 
 #include "dm2_device_math.h"
+#include "dm2_stamps.h"
 #include "dm2_state.h"
+
+#ifdef DM2_STAMPS
+namespace dm2 {
+unsigned long long* stamps_table() {
+    static unsigned long long* p = nullptr;
+    if (!p) { (void)hipMalloc((void**)&p, 2 * DM2_NSTAMP * sizeof(unsigned long long)); (void)hipMemset(p, 0, 2 * DM2_NSTAMP * sizeof(unsigned long long)); }
+    return p;
+}
+}  // namespace dm2
+#endif
 
 namespace {
 
@@ -98,6 +109,20 @@ int dm2_profile_read(float* ms, int capacity) {
         if (hipEventElapsedTime(&t, p.ev[2 * s], p.ev[2 * s + 1]) == hipSuccess) ms[s] = t;
     }
     return n;
+}
+
+int dm2_debug_stamps(uint64_t* out, int capacity, int reset) {
+#ifdef DM2_STAMPS
+    unsigned long long h[2][DM2_NSTAMP];
+    if (hipMemcpy(h, dm2::stamps_table(), sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    int n = 0;
+    for (int k = 0; k < 2; k++) for (int i = 0; i < DM2_NSTAMP && n < capacity; i++) out[n++] = h[k][i];
+    if (reset) (void)hipMemset(dm2::stamps_table(), 0, sizeof(h));
+    return n;
+#else
+    (void)out; (void)capacity; (void)reset;
+    return -1;
+#endif
 }
 
 int dm2_abi_version(void) { return DM2_ABI_VERSION; }

@@ -12,14 +12,16 @@
 //      per-(tile,entry) accumulators; flushed per chunk with (entry,component) atomics.
 #include <hip/hip_runtime.h>
 
+#include "dm2_clip_lds.h"
 #include "dm2_device_math.h"
 #include "dm2_pairs.h"
 #include "dm2_stage.h"
+#include "dm2_stamps.h"
 #include "dm2_state.h"
 
 namespace dm2 {
 
-constexpr int BD_CHUNK = 128;
+constexpr int BD_CHUNK = 64;
 constexpr int BD_ACC = 32;
 constexpr int B_DV = 0, B_DC = 9, B_DZ = 18, B_OP = 21, B_IN = 22, B_AA = 23, B_N = 29, B_FLAG = 31;
 constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
@@ -32,7 +34,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                         float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
-                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts) {
+                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts STAMP_PARAM) {
     __shared__ FaceRec recs[BD_CHUNK];
     __shared__ float acc[BD_CHUNK * BD_ACC];
     __shared__ BwdPair s_pair[2][TILE_PIX];
@@ -41,11 +43,19 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     __shared__ int s_off[BD_CHUNK + 1];
     __shared__ uint32_t s_rect[BD_CHUNK];
     __shared__ int s_wave[4];
+    __shared__ int s_inv[17];
+    __shared__ unsigned long long s_mask[2][TILE_PIX];   // per pixel: faces of the current batch that blend into it
+    __shared__ uint32_t s_ovf[2][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
+    __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
+    __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
     __shared__ uint32_t s_max_lc;
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     const int tid = threadIdx.x;
+    STAMP_DECL
+    fill_inv_table(s_inv);
+    s_mask[0][tid] = 0; s_mask[1][tid] = 0; s_ovf[0][tid] = 0; s_ovf[1][tid] = 0;
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -90,8 +100,10 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_recd = 0.f;
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
 
+    STAMP(0)
     for (int base = 0; base < total; base += BD_CHUNK) {
         __syncthreads();                                            // previous chunk flushed, LDS reusable
+        STAMP(1)
         const int n = min(BD_CHUNK, total - base);
         int cnt = 0;
         if (tid < n) {
@@ -101,12 +113,14 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
             s_rect[tid] = rect;
         }
+        STAMP(2)
         for (int k = tid; k < n * BD_ACC; k += TILE_PIX) acc[k] = 0.f;
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
         if (tid < n) s_off[tid] = ex;
         if (tid == n) s_off[n] = tot;
         __syncthreads();
+        STAMP(3)
         const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
 
         for (int bi = 0; bi < nb; bi++) {
@@ -122,7 +136,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 j = find_face(s_off, n, k);
                 const uint32_t rect = s_rect[j];
                 int qx, qy;
-                pair_xy(rect, k - s_off[j], qx, qy);
+                pair_xy(rect, k - s_off[j], s_inv, qx, qy);
                 q = qy * TILE + qx;
                 const FaceRec& fc = recs[j];
                 const float pxmin = (float)(uint32_t)(X0a + qx), pxmax = pxmin + 1;
@@ -130,7 +144,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 float oarea = 0.f;
                 bool live = true;
                 if (use_aa) {
-                    const int err = tri_pix_overlap_area<true>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, dg);
+                    const int err = tri_pix_overlap_area_lds<true>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
                     live = !((err != 0) || (oarea == 0.0f));
                 }
                 BwdPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
@@ -159,14 +173,31 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     }
                 }
                 s_pair[bi & 1][tid] = out;
+                if (blend) {
+                    const int bit = j - find_face(s_off, n, bi * TILE_PIX);
+                    if (bit < 64) atomicOr(&s_mask[bi & 1][q], 1ull << bit);
+                    else s_ovf[bi & 1][q] = 1;
+                }
             }
+            STAMP(4)
             __syncthreads();
+            STAMP(5)
 
             // ---- phase C: per-pixel back-to-front replay ------------------------------------
-            if (inside) {
+            {
                 const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
-                const int jlo = find_face(s_off, n, k0), jhi = find_face(s_off, n, k1 - 1);
-                for (int jj = jlo; jj <= jhi; jj++) {
+                unsigned long long m = s_mask[bi & 1][tid];
+                s_mask[bi & 1][tid] = 0;
+                const bool ovf = s_ovf[bi & 1][tid] != 0;
+                s_ovf[bi & 1][tid] = 0;
+                const int jlo = find_face(s_off, n, k0);
+                const int jhi = ovf ? find_face(s_off, n, k1 - 1) : jlo;
+                int jover = jlo + 64;
+                // faces flagged in the mask first (ascending = back to front), then any beyond the 64 mask bits
+                while (m || (ovf && jover <= jhi)) {
+                    int jj;
+                    if (m) { jj = jlo + __ffsll((long long)m) - 1; m &= m - 1; }
+                    else jj = jover++;
                     const uint32_t e = (uint32_t)(total - 1 - base - jj);        // 0-based position in the list
                     if (e >= last_contributor) continue;                          // backward.cu:219-221
                     const int o = s_off[jj];
@@ -202,7 +233,9 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     pr.T = T; pr.dL_dalpha = dL_dalpha; pr.flags = BF_BLEND | BF_ACTIVE;
                 }
             }
+            STAMP(6)
             __syncthreads();
+            STAMP(8)
 
             // ---- phase D: chain rule + per-entry accumulation -------------------------------
             if (have && blend) {
@@ -260,8 +293,10 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     a[B_FLAG] = 1.0f;
                 }
             }
+            STAMP(9)
         }
         __syncthreads();
+        STAMP(10)
 
         // ---- flush: lane = (entry, component); 8 entries per pass --------------------------
         const int comp = tid & 31;
@@ -281,7 +316,9 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 atomicAdd(dst, val);
             }
         }
+        STAMP(11)
     }
+    STAMP_FLUSH
 }
 
 void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
@@ -291,7 +328,7 @@ void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges,
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts);
+                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts STAMP_ARG(1));
 }
 
 }  // namespace dm2

@@ -8,9 +8,11 @@
 // list order.  One barrier per batch of 256 pairs (pair records double buffered).
 #include <hip/hip_runtime.h>
 
+#include "dm2_clip_lds.h"
 #include "dm2_device_math.h"
 #include "dm2_pairs.h"
 #include "dm2_stage.h"
+#include "dm2_stamps.h"
 #include "dm2_state.h"
 
 namespace dm2 {
@@ -24,17 +26,25 @@ struct __attribute__((aligned(8))) FwdPair { float alpha, c0, c1, c2, depth; uin
 __global__ void __launch_bounds__(TILE_PIX)
 k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
-                       int32_t* __restrict__ out_tri_cnt) {
+                       int32_t* __restrict__ out_tri_cnt STAMP_PARAM) {
     __shared__ FaceRec recs[FD_CHUNK];
     __shared__ FwdPair s_pair[2][TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ int s_off[FD_CHUNK + 1];
     __shared__ uint32_t s_rect[FD_CHUNK];
     __shared__ int s_wave[4];
+    __shared__ int s_inv[17];
+    __shared__ unsigned long long s_mask[2][TILE_PIX];   // per pixel: faces of the current batch that produced a pair for it
+    __shared__ uint32_t s_ovf[2][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
+    __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
+    __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     const int tid = threadIdx.x;
+    STAMP_DECL
+    fill_inv_table(s_inv);
+    s_mask[0][tid] = 0; s_mask[1][tid] = 0; s_ovf[0][tid] = 0; s_ovf[1][tid] = 0;
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -65,8 +75,10 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     int rec_cnt = 0;
 
+    STAMP(0)
     for (int base = 0; base < total; base += FD_CHUNK) {
         if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260; also fences LDS reuse
+        STAMP(1)
         const int n = min(FD_CHUNK, total - base);
         int cnt = 0;
         if (tid < n) {
@@ -75,21 +87,24 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
             s_rect[tid] = rect;
         }
+        STAMP(2)
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
         if (tid < n) s_off[tid] = ex;
         if (tid == n) s_off[n] = tot;
         __syncthreads();
+        STAMP(3)
         const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
 
         // ---- phase B: one pair per lane ------------------------------------------------
         auto eval_batch = [&](int bi) {
             const int k = bi * TILE_PIX + tid;
             if (k >= tot) return;
+            const int jlo_b = find_face(s_off, n, bi * TILE_PIX);      // first face of this batch (block uniform)
             const int j = find_face(s_off, n, k);
             const uint32_t rect = s_rect[j];
             int qx, qy;
-            pair_xy(rect, k - s_off[j], qx, qy);
+            pair_xy(rect, k - s_off[j], s_inv, qx, qy);
             const int q = qy * TILE + qx;
             const FaceRec& fc = recs[j];
             const float pxmin = (float)(uint32_t)(X0a + qx), pxmax = pxmin + 1;
@@ -98,7 +113,7 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             float oarea = 0.f;
             bool live = true;
             if (use_aa) {
-                const int err = tri_pix_overlap_area<false>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, nullptr);
+                const int err = tri_pix_overlap_area_lds<false>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, nullptr);
                 live = !((err != 0) || (oarea == 0.0f));
                 if (live) out.flags |= PF_REC;
             }
@@ -125,33 +140,57 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 }
             }
             s_pair[bi & 1][tid] = out;
+            if (out.flags) {
+                // tell pixel q which faces of this batch it has to look at (bit = face - first face of batch)
+                const int bit = j - jlo_b;
+                if (bit < 64) atomicOr(&s_mask[bi & 1][q], 1ull << bit);
+                else s_ovf[bi & 1][q] = 1;
+            }
         };
 
         if (nb > 0) eval_batch(0);
+        STAMP(4)
         for (int bi = 0; bi < nb; bi++) {
             __syncthreads();
+            STAMP(5)
             // ---- phase C: ordered blend of this pixel's pairs of batch bi ---------------
-            if (!done) {
+            {
                 const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
-                const int jlo = find_face(s_off, n, k0), jhi = find_face(s_off, n, k1 - 1);
-                for (int j = jlo; j <= jhi; j++) {
+                unsigned long long m = s_mask[bi & 1][tid];
+                s_mask[bi & 1][tid] = 0;                                   // ready for batch bi+2
+                const bool ovf = s_ovf[bi & 1][tid] != 0;
+                s_ovf[bi & 1][tid] = 0;
+                const int jlo = find_face(s_off, n, k0);
+                auto blend_face = [&](int j) -> bool {                    // returns true when the pixel terminates
                     const int o = s_off[j];
-                    if (s_off[j + 1] == o) continue;
+                    if (s_off[j + 1] == o) return false;
                     const int k = pixel_pair(s_rect[j], o, lx, ly);
-                    if (k < k0 || k >= k1) continue;
+                    if (k < k0 || k >= k1) return false;
                     const FwdPair pr = s_pair[bi & 1][k - k0];
                     if ((pr.flags & PF_REC) && rec_cnt < K) rec_cnt++;       // forward.cu:344-352
-                    if (!(pr.flags & PF_BLEND)) continue;
+                    if (!(pr.flags & PF_BLEND)) return false;
                     const float alpha = pr.alpha;
                     const float test_T = T * (1 - alpha);
                     C0 += pr.c0 * alpha * T; C1 += pr.c1 * alpha * T; C2 += pr.c2 * alpha * T;
                     D += pr.depth * alpha * T;
                     pT = T; T = test_T;
                     last_contributor = (uint32_t)(base + j + 1);
-                    if (T < T_EPS) { done = true; break; }
+                    return T < T_EPS;
+                };
+                while (m && !done) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (blend_face(jlo + bit)) done = true;
+                }
+                if (ovf) {                                                 // > 64 faces in one batch: plain walk of the rest
+                    const int jhi = find_face(s_off, n, k1 - 1);
+                    for (int j = jlo + 64; j <= jhi && !done; j++)
+                        if (blend_face(j)) done = true;
                 }
             }
+            STAMP(6)
             if (bi + 1 < nb) eval_batch(bi + 1);
+            STAMP(4)
         }
     }
 
@@ -165,13 +204,15 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         out_depth[pix] = D + T * 1.0f;
         if (out_tri_cnt) out_tri_cnt[pix] = rec_cnt;
     }
+    STAMP(7)
+    STAMP_FLUSH
 }
 
 void launch_render_forward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_FWD, st);
-    hipLaunchKernelGGL(k_render_forward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt);
+    hipLaunchKernelGGL(k_render_forward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt STAMP_ARG(0));
 }
 
 }  // namespace dm2

@@ -76,9 +76,13 @@ __device__ __forceinline__ int find_face(const int* off, int n, int k) {
 }
 
 // local pair index -> (dx, dy) inside a rectangle of width w <= 16 (local < 256)
-__device__ __forceinline__ void pair_xy(uint32_t rect, int local, int& lx, int& ly) {
+// inv_w[w] = ceil(65536 / w), w = 1..16 (LDS table filled by fill_inv_table)
+__device__ __forceinline__ void fill_inv_table(int* inv_w) {
+    if (threadIdx.x >= 1 && threadIdx.x <= 16) inv_w[threadIdx.x] = (65536 + (int)threadIdx.x - 1) / (int)threadIdx.x;
+}
+__device__ __forceinline__ void pair_xy(uint32_t rect, int local, const int* inv_w, int& lx, int& ly) {
     const int w = (int)((rect >> 8) & 15u) + 1;
-    const int inv = (65536 + w - 1) / w;           // exact floor(local / w) for local < 256, w <= 16
+    const int inv = inv_w[w];                      // (local * inv) >> 16 == floor(local / w) for local < 256, w <= 16
     const int dy = (local * inv) >> 16;
     lx = (int)(rect & 15u) + (local - dy * w);
     ly = (int)((rect >> 4) & 15u) + dy;

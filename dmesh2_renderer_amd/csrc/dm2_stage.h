@@ -3,7 +3,7 @@
 // The reference stages 96-108 B per entry in shared memory and re-reads the AA
 // tables from global memory for every (pixel,face) (forward.cu:228-243,314-317,
 // aa.h:111-120,184-203).  Here everything a (pixel,face) evaluation needs is
-// gathered ONCE per (tile,entry) into a 256-byte LDS record; the per-pixel loop
+// gathered ONCE per (tile,entry) into a 272-byte LDS record; the per-pixel loop
 // then reads it with wave-uniform (broadcast) ds_reads only.
 #pragma once
 #include "dm2_device_math.h"
@@ -19,9 +19,10 @@ struct __attribute__((aligned(16))) FaceRec {
     float opacity, intense;
     int face_id;
     int vid[3];         // vertex ids (backward scatter)
-    float pad[5];
+    float pad[9];       // 272-B stride: records of consecutive entries start 4 LDS banks apart, so lanes that
+                        // read the same field of different records do not collide (256 B would be a 64-way conflict)
 };
-static_assert(sizeof(FaceRec) == 256, "FaceRec must be 256 B");
+static_assert(sizeof(FaceRec) == 272, "FaceRec must be 272 B");
 
 // Gather entry `face_id` of view `b` into `r` (one lane per record).
 __device__ __forceinline__ void stage_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {

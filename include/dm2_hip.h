@@ -159,6 +159,11 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
 void dm2_profile_enable(int on);
 int dm2_profile_read(float* ms, int capacity);
 
+/* Diagnostic builds only (-DDM2_STAMPS): copy the in-kernel cycle-stamp table (2 kernels x 16
+ * segments, shader cycles summed over waves) to the HOST array `out`; returns the number of
+ * values, or -1 in a product build (which contains no stamps). */
+int dm2_debug_stamps(uint64_t* out, int capacity, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 //      per-(tile,entry) accumulators; flushed per chunk with (entry,component) atomics.
 #include <hip/hip_runtime.h>
 
+#include "dm2_clip_grad.h"
 #include "dm2_clip_lds.h"
 #include "dm2_device_math.h"
 #include "dm2_pairs.h"
@@ -144,7 +145,11 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 float oarea = 0.f;
                 bool live = true;
                 if (use_aa) {
+#ifdef DM2_BWD_FAN_GRAD     // reference's per-fan-triangle accumulation order (slower; kept for A/B)
                     const int err = tri_pix_overlap_area_lds<true>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
+#else
+                    const int err = tri_pix_overlap_area_grad(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
+#endif
                     live = !((err != 0) || (oarea == 0.0f));
                 }
                 BwdPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;

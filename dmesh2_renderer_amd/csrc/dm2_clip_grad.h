@@ -1,0 +1,177 @@
+// dm2_clip_grad.h -- overlap area of a CCW triangle and a unit pixel AND its Jacobian
+// w.r.t. the triangle's corners (aa.h:151-441), for the backward pass on gfx950.
+//
+// Construction of the clipped polygon is the straight-line code of dm2_clip_area.h (same
+// corners, same order, same fan sum -> the AREA is bit-identical to the forward's, which
+// the backward relies on to replay the forward's decisions).  Corners are additionally
+// written to a per-lane, lane-strided LDS table with a 4-bit kind code each.
+//
+// Gradient: the reference differentiates its fan sum triangle by triangle
+// (aa.h:415-433), i.e. every polygon corner c_i receives d(fan triangle)/d(c_i) from up
+// to all fan triangles it belongs to, each pushed through the corner's Jacobian J_i
+// separately.  Summed over the fan these partials telescope to the shoelace form
+//       dA/dc_i = 1/2 * ( y_{i+1} - y_{i-1},  x_{i-1} - x_{i+1} )      (cyclic),
+// so here each corner is pushed through J_i ONCE with that vector.  This is the same
+// polynomial in the same inputs, regrouped: results differ from the reference's order of
+// fp32 additions at the 1e-7 relative level (the gradients are accumulated with atomics
+// afterwards, whose order is not reproducible either); DESIGN.md lists it as the one
+// place where the backward departs from the reference's operation order.
+#pragma once
+#include "dm2_clip_area.h"
+#include "dm2_clip_lds.h"
+#include "dm2_device_math.h"
+
+namespace dm2 {
+
+struct TabState {
+    FanState fan;
+    uint64_t codes;
+};
+
+__device__ __forceinline__ void tab_push(TabState& S, bool en, float x, float y, uint32_t code, float* polyx, float* polyy) {
+    const int slot = S.fan.cnt;
+    if (en && slot < MAX_POLY) {
+        polyx[slot * POLY_STRIDE] = x; polyy[slot * POLY_STRIDE] = y;
+        S.codes |= (uint64_t)code << (4 * slot);
+    }
+    fan_push(S.fan, en, x, y);
+}
+
+template <int TI>
+__device__ __forceinline__ void clip_edge_tab(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                              uint32_t inside, TabState& S, float* polyx, float* polyy) {
+    constexpr int TJ = (TI + 1) % 3;
+    constexpr uint32_t ecode = (uint32_t)TI << 2;
+    const float p0x = f.v[2 * TI], p0y = f.v[2 * TI + 1], p1x = f.v[2 * TJ], p1y = f.v[2 * TJ + 1];
+    const float ex = f.e[2 * TI], ey = f.e[2 * TI + 1], rx = f.r[2 * TI], ry = f.r[2 * TI + 1];
+    const bool e_vertical = (f.zmask >> (2 * TI)) & 1u, e_horizontal = (f.zmask >> (2 * TI + 1)) & 1u;
+    const bool p0in = (p0x >= pxmin) && (p0x <= pxmax) && (p0y >= pymin) && (p0y <= pymax);
+    const bool p1in = (p1x >= pxmin) && (p1x <= pxmax) && (p1y >= pymin) && (p1y <= pymax);
+    const float tA = (pymin - p0y) * ry, xA = p0x + tA * ex;
+    const float tB = (pxmax - p0x) * rx, yB = p0y + tB * ey;
+    const float tC = (pymax - p0y) * ry, xC = p0x + tC * ex;
+    const float tD = (pxmin - p0x) * rx, yD = p0y + tD * ey;
+    const bool vA = (tA >= 0) && (tA <= 1) && (xA >= pxmin) && (xA <= pxmax) && !e_horizontal;
+    const bool vB = (tB >= 0) && (tB <= 1) && (yB >= pymin) && (yB <= pymax) && !e_vertical;
+    const bool vC = (tC >= 0) && (tC <= 1) && (xC >= pxmin) && (xC <= pxmax) && !e_horizontal;
+    const bool vD = (tD >= 0) && (tD <= 1) && (yD >= pymin) && (yD <= pymax) && !e_vertical;
+    const bool e00 = (vA && ((xA == pxmin) || (xA == pxmax))) || (vB && ((yB == pymin) || (yB == pymax))) ||
+                     (vC && ((xC == pxmin) || (xC == pxmax))) || (vD && ((yD == pymin) || (yD == pymax)));
+    const int n = (int)vA + (int)vB + (int)vC + (int)vD;
+    const float x0 = vA ? xA : (vB ? pxmax : (vC ? xC : pxmin));
+    const float y0 = vA ? pymin : (vB ? yB : (vC ? pymax : yD));
+    const float t0 = vA ? tA : (vB ? tB : (vC ? tC : tD));
+    const int pe0 = vA ? 0 : (vB ? 1 : (vC ? 2 : 3));
+    const float x1 = vD ? pxmin : (vC ? xC : pxmax);
+    const float y1 = vD ? yD : (vC ? pymax : yB);
+    const float t1 = vD ? tD : (vC ? tC : tB);
+    const int pe1 = vD ? 3 : (vC ? 2 : 1);
+    const uint32_t k0 = (pe0 & 1) ? PK_XV : PK_XH, k1 = (pe1 & 1) ? PK_XV : PK_XH;
+    const bool two = (n == 2), one = (n == 1), none = (n == 0);
+    const bool sw = two && (t0 > t1);
+    S.fan.err = S.fan.err || e00 || (n > 2) || (one && (p0in == p1in)) || (none && (p0in != p1in));
+    const bool en1 = two || one || (none && p0in && p1in);
+    const float ax = two ? (sw ? x1 : x0) : (one ? x0 : p1x);
+    const float ay = two ? (sw ? y1 : y0) : (one ? y0 : p1y);
+    const uint32_t ac = (two ? (sw ? k1 : k0) : (one ? k0 : PK_TRIV)) | ecode;
+    tab_push(S, en1 && !S.fan.err, ax, ay, ac, polyx, polyy);
+    const bool en2 = two || (one && !p0in && p1in);
+    const float bx = two ? (sw ? x0 : x1) : p1x;
+    const float by = two ? (sw ? y0 : y1) : p1y;
+    const uint32_t bc = (two ? (sw ? k0 : k1) : PK_TRIV) | ecode;
+    tab_push(S, en2 && !S.fan.err, bx, by, bc, polyx, polyy);
+    const bool walk = two || (one && p0in && !p1in);
+    const int final_pe = two ? (sw ? pe0 : pe1) : pe0;
+    bool go = walk && !S.fan.err;
+#pragma unroll
+    for (int pvi = 0; pvi < 4; pvi++) {
+        const int cur = (final_pe + 1 + pvi) & 3;
+        go = go && ((inside >> cur) & 1u);
+        const float cx = (cur == 1 || cur == 2) ? pxmax : pxmin;
+        const float cy = (cur >= 2) ? pymax : pymin;
+        tab_push(S, go, cx, cy, PK_CORNER, polyx, polyy);
+    }
+}
+
+// Push dA/dc = (gax, gay) of one polygon corner through its Jacobian (aa.h:67-86, :276-294).
+// Straight-line: edge data selected from registers by the corner's edge index.
+__device__ __forceinline__ void corner_grad_sel(const AAFace& f, uint32_t code, float x, float y, float gax, float gay, float* g) {
+    const uint32_t kind = code & 3u;
+    const int ti = (int)(code >> 2);
+    const int tj = ti == 2 ? 0 : ti + 1;
+    const float ex = ti == 0 ? f.e[0] : (ti == 1 ? f.e[2] : f.e[4]);
+    const float ey = ti == 0 ? f.e[1] : (ti == 1 ? f.e[3] : f.e[5]);
+    const bool xh = kind == PK_XH;
+    // along-axis quantities: axis0 = y for a crossing of a y=const pixel edge, x otherwise
+    const float p0a = xh ? (ti == 0 ? f.v[1] : (ti == 1 ? f.v[3] : f.v[5])) : (ti == 0 ? f.v[0] : (ti == 1 ? f.v[2] : f.v[4]));
+    const float p1a = xh ? (tj == 0 ? f.v[1] : (tj == 1 ? f.v[3] : f.v[5])) : (tj == 0 ? f.v[0] : (tj == 1 ? f.v[2] : f.v[4]));
+    const float ra = xh ? (ti == 0 ? f.r[1] : (ti == 1 ? f.r[3] : f.r[5])) : (ti == 0 ? f.r[0] : (ti == 1 ? f.r[2] : f.r[4]));
+    const float ia = xh ? y : x;
+    const float t = (ia - p0a) * ra;
+    const float gt0 = (ia - p1a) * ra * ra;
+    const float gt1 = (-ia + p0a) * ra * ra;
+    const float omt = (float)(1.0 - (double)t);
+    // crossing Jacobians, see dm2_clip_lds.h corner_grad for the derivation of the two layouts
+    const float a0_h = omt * gax, a1_h = (gt0 * ex) * gax + one_minus_t_plus(t, gt0 * ey) * gay;
+    const float b0_h = t * gax, b1_h = (gt1 * ex) * gax + (t + (gt1 * ey)) * gay;
+    const float a0_v = one_minus_t_plus(t, gt0 * ex) * gax + (gt0 * ey) * gay, a1_v = omt * gay;
+    const float b0_v = (t + (gt1 * ex)) * gax + (gt1 * ey) * gay, b1_v = t * gay;
+    const bool cross = kind >= PK_XH;
+    const bool triv = kind == PK_TRIV;
+    const float a0 = cross ? (xh ? a0_h : a0_v) : 0.f, a1 = cross ? (xh ? a1_h : a1_v) : 0.f;
+    const float b0 = cross ? (xh ? b0_h : b0_v) : (triv ? gax : 0.f), b1 = cross ? (xh ? b1_h : b1_v) : (triv ? gay : 0.f);
+    const int rowa = cross ? ti : -1;                 // triangle vertex: only the (0, I) block acts (row tj)
+    const int rowb = (cross || triv) ? tj : -1;       // pixel corner: nothing
+    rows_add(g, rowa, a0, a1);
+    rows_add(g, rowb, b0, b1);
+}
+
+// aa.h:446-504 with Jacobian.  Returns non-zero on any reference error; area / g valid when 0.
+__device__ __forceinline__ int tri_pix_overlap_area_grad(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                                         float pix_area, float* polyx, float* polyy, float& area, float* g) {
+    area = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) g[k] = 0.f;
+    if ((pxmax < f.bb[0]) || (pxmin > f.bb[1]) || (pymax < f.bb[2]) || (pymin > f.bb[3])) return 0;
+    uint32_t inside = 0xF;
+    bool outside = false;
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++) {
+        const float nx = f.n[2 * ti], ny = f.n[2 * ti + 1], c = f.c[ti];
+        const bool i0 = (pxmin * nx) + (pymin * ny) - c >= 0;
+        const bool i1 = (pxmax * nx) + (pymin * ny) - c >= 0;
+        const bool i2 = (pxmax * nx) + (pymax * ny) - c >= 0;
+        const bool i3 = (pxmin * nx) + (pymax * ny) - c >= 0;
+        outside = outside || !(i0 || i1 || i2 || i3);
+        inside &= (uint32_t)i0 | ((uint32_t)i1 << 1) | ((uint32_t)i2 << 2) | ((uint32_t)i3 << 3);
+    }
+    if (outside) return 0;
+    if (inside == 0xF) { area = pix_area; return 0; }                 // aa.h:493-496: zero Jacobian
+#ifdef DM2_ABLATE_CLIP
+    area = 0.5f * pix_area; return 0;
+#endif
+    TabState S;
+    S.fan.fx = S.fan.fy = S.fan.px = S.fan.py = 0.f; S.fan.area = 0.f; S.fan.cnt = 0; S.fan.err = false; S.codes = 0;
+    clip_edge_tab<0>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
+    clip_edge_tab<1>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
+    clip_edge_tab<2>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
+    if (S.fan.err) return 1;
+    if (S.fan.area > pix_area) return 6;
+    area = S.fan.area;
+    const int cnt = S.fan.cnt;
+    if (cnt < 3 || area == 0.0f) return 0;        // no fan triangle: zero Jacobian (and the caller skips area 0)
+    // shoelace gradient, corner by corner
+    float xm = polyx[(cnt - 1) * POLY_STRIDE], ym = polyy[(cnt - 1) * POLY_STRIDE];   // c_{i-1}
+    float xc = S.fan.fx, yc = S.fan.fy;                                               // c_i   (c_0 == first)
+#pragma unroll 1
+    for (int i = 0; i < cnt; i++) {
+        const int nxt = (i + 1 == cnt) ? 0 : i + 1;
+        const float xn = polyx[nxt * POLY_STRIDE], yn = polyy[nxt * POLY_STRIDE];
+        const uint32_t code = (uint32_t)((S.codes >> (4 * i)) & 15u);
+        corner_grad_sel(f, code, xc, yc, 0.5f * (yn - ym), 0.5f * (xm - xn), g);
+        xm = xc; ym = yc; xc = xn; yc = yn;
+    }
+    return 0;
+}
+
+}  // namespace dm2

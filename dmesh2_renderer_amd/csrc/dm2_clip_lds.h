@@ -92,6 +92,9 @@ __device__ __forceinline__ int tri_pix_overlap_area_lds(const AAFace& f, float p
     }
     if (outside) return 0;
     if (inside == 0xF) { area = pix_area; return 0; }
+#ifdef DM2_ABLATE_CLIP   // diagnostic only: price of the polygon clip
+    area = 0.5f * pix_area; return 0;
+#endif
 
     int cnt = 0;
     uint64_t codes = 0;

@@ -8,6 +8,7 @@
 // list order.  One barrier per batch of 256 pairs (pair records double buffered).
 #include <hip/hip_runtime.h>
 
+#include "dm2_clip_area.h"
 #include "dm2_clip_lds.h"
 #include "dm2_device_math.h"
 #include "dm2_pairs.h"
@@ -36,8 +37,10 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ int s_inv[17];
     __shared__ unsigned long long s_mask[2][TILE_PIX];   // per pixel: faces of the current batch that produced a pair for it
     __shared__ uint32_t s_ovf[2][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
+#ifdef DM2_FWD_LDS_CLIP
     __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
     __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
+#endif
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -113,7 +116,13 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             float oarea = 0.f;
             bool live = true;
             if (use_aa) {
+#if defined(DM2_FWD_LDS_CLIP)
                 const int err = tri_pix_overlap_area_lds<false>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, nullptr);
+#elif defined(DM2_FWD_REG_CLIP)
+                const int err = tri_pix_overlap_area<false>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, nullptr);
+#else
+                const int err = tri_pix_overlap_area_only(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea);
+#endif
                 live = !((err != 0) || (oarea == 0.0f));
                 if (live) out.flags |= PF_REC;
             }

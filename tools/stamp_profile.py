@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dmesh2_renderer_amd import _C  # noqa: E402
 
-_C.LIB_PATH = os.path.join(ROOT, "dmesh2_renderer_amd", "csrc", "libdm2_hip_stamps.so")
+_C.LIB_PATH = os.path.join(ROOT, "dmesh2_renderer_amd", "csrc", os.environ.get("DM2_STAMP_LIB", "libdm2_hip_stamps.so"))
 import bench  # noqa: E402
 
 FWD = ["prologue", "top barrier", "stage faces", "scan+barrier", "phase B (pairs)", "barrier after B", "phase C (blend)", "epilogue"]

@@ -22,7 +22,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdm2_hip.so")
+LIB_PATH = os.environ.get("DM2_HIP_LIB") or os.path.join(_HERE, "csrc", "libdm2_hip.so")   # env override: A/B builds
 _lib = None
 _lock = threading.Lock()
 

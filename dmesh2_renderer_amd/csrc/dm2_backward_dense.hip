@@ -22,7 +22,18 @@
 
 namespace dm2 {
 
-constexpr int BD_CHUNK = 64;
+#ifndef DM2_BD_CHUNK
+#define DM2_BD_CHUNK 28   // with NBUF 1 the block needs 53.5 KB LDS / <=168 VGPRs -> 3 blocks per CU.  A/B at cfg4 on MI355X:
+                          // chunk 64 / 2 buffers (2 blocks/CU) 6.37 ms, chunk 32 / 2 buffers 6.68 ms, chunk 28 / 1 buffer / 3 blocks 5.64 ms
+#endif
+constexpr int BD_CHUNK = DM2_BD_CHUNK;
+#ifndef DM2_BD_NBUF
+#define DM2_BD_NBUF 1
+#endif
+constexpr int BD_NBUF = DM2_BD_NBUF;          // 2: pair records double buffered (2 barriers / batch); 1: single (3 barriers, 12 KB less LDS)
+#ifndef DM2_BD_WAVES
+#define DM2_BD_WAVES 3
+#endif
 constexpr int BD_ACC = 32;
 constexpr int B_DV = 0, B_DC = 9, B_DZ = 18, B_OP = 21, B_IN = 22, B_AA = 23, B_N = 29, B_FLAG = 31;
 constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
@@ -30,7 +41,7 @@ constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
 struct __attribute__((aligned(16))) BwdPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BwdPair) == 32, "BwdPair");
 
-__global__ void __launch_bounds__(TILE_PIX)
+__global__ void __launch_bounds__(TILE_PIX, DM2_BD_WAVES)
 k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
@@ -38,15 +49,15 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts STAMP_PARAM) {
     __shared__ FaceRec recs[BD_CHUNK];
     __shared__ float acc[BD_CHUNK * BD_ACC];
-    __shared__ BwdPair s_pair[2][TILE_PIX];
+    __shared__ BwdPair s_pair[BD_NBUF][TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ float s_dL[TILE_PIX * 4];
     __shared__ int s_off[BD_CHUNK + 1];
     __shared__ uint32_t s_rect[BD_CHUNK];
     __shared__ int s_wave[4];
     __shared__ int s_inv[17];
-    __shared__ unsigned long long s_mask[2][TILE_PIX];   // per pixel: faces of the current batch that blend into it
-    __shared__ uint32_t s_ovf[2][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
+    __shared__ unsigned long long s_mask[BD_NBUF][TILE_PIX];   // per pixel: faces of the current batch that blend into it
+    __shared__ uint32_t s_ovf[BD_NBUF][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
     __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
     __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
     __shared__ uint32_t s_max_lc;
@@ -56,7 +67,8 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     const int tid = threadIdx.x;
     STAMP_DECL
     fill_inv_table(s_inv);
-    s_mask[0][tid] = 0; s_mask[1][tid] = 0; s_ovf[0][tid] = 0; s_ovf[1][tid] = 0;
+#pragma unroll
+    for (int u = 0; u < BD_NBUF; u++) { s_mask[u][tid] = 0; s_ovf[u][tid] = 0; }
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -177,11 +189,11 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         }
                     }
                 }
-                s_pair[bi & 1][tid] = out;
+                s_pair[bi & (BD_NBUF - 1)][tid] = out;
                 if (blend) {
                     const int bit = j - find_face(s_off, n, bi * TILE_PIX);
-                    if (bit < 64) atomicOr(&s_mask[bi & 1][q], 1ull << bit);
-                    else s_ovf[bi & 1][q] = 1;
+                    if (bit < 64) atomicOr(&s_mask[bi & (BD_NBUF - 1)][q], 1ull << bit);
+                    else s_ovf[bi & (BD_NBUF - 1)][q] = 1;
                 }
             }
             STAMP(4)
@@ -191,10 +203,10 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             // ---- phase C: per-pixel back-to-front replay ------------------------------------
             {
                 const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
-                unsigned long long m = s_mask[bi & 1][tid];
-                s_mask[bi & 1][tid] = 0;
-                const bool ovf = s_ovf[bi & 1][tid] != 0;
-                s_ovf[bi & 1][tid] = 0;
+                unsigned long long m = s_mask[bi & (BD_NBUF - 1)][tid];
+                s_mask[bi & (BD_NBUF - 1)][tid] = 0;
+                const bool ovf = s_ovf[bi & (BD_NBUF - 1)][tid] != 0;
+                s_ovf[bi & (BD_NBUF - 1)][tid] = 0;
                 const int jlo = find_face(s_off, n, k0);
                 const int jhi = ovf ? find_face(s_off, n, k1 - 1) : jlo;
                 int jover = jlo + 64;
@@ -209,7 +221,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     if (s_off[jj + 1] == o) continue;
                     const int kk = pixel_pair(s_rect[jj], o, lx, ly);
                     if (kk < k0 || kk >= k1) continue;
-                    BwdPair& pr = s_pair[bi & 1][kk - k0];
+                    BwdPair& pr = s_pair[bi & (BD_NBUF - 1)][kk - k0];
                     if (!(pr.flags & BF_BLEND)) continue;
                     const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
                     if (!T_first_pass) T = T / (1.f - a);                         // backward.cu:340-348
@@ -244,7 +256,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
 
             // ---- phase D: chain rule + per-entry accumulation -------------------------------
             if (have && blend) {
-                const BwdPair pr = s_pair[bi & 1][tid];
+                const BwdPair pr = s_pair[bi & (BD_NBUF - 1)][tid];
                 if (pr.flags & BF_ACTIVE) {
                     const FaceRec& fc = recs[j];
                     const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
@@ -299,6 +311,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 }
             }
             STAMP(9)
+            if (BD_NBUF == 1) __syncthreads();      // single-buffered pair records: D(b) must finish before B(b+1) overwrites them
         }
         __syncthreads();
         STAMP(10)

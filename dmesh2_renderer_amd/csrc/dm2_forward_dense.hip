@@ -18,7 +18,10 @@
 
 namespace dm2 {
 
-constexpr int FD_CHUNK = 128;
+#ifndef DM2_FD_CHUNK
+#define DM2_FD_CHUNK 48   // A/B on MI355X at cfg4: 32: 1.23 ms, 48: 1.15, 64: 1.34, 96: 1.31, 128: 1.72 (LDS-limited occupancy)
+#endif
+constexpr int FD_CHUNK = DM2_FD_CHUNK;
 constexpr uint32_t PF_REC = 1u;      // AA overlap found (the reference takes an AA record here)
 constexpr uint32_t PF_BLEND = 2u;    // the face blends into the pixel
 

@@ -1,0 +1,191 @@
+"""GPU tests at the BASELINE.json configuration sizes.
+
+The oracle cannot walk a full 1080p / 1M-triangle frame in test time, so config 4 is checked through
+size-independent properties of the domain (band decomposition == full frame bit for bit, the gradient
+of a sum of band losses == the full-frame gradient, linearity of the backward in the upstream gradient,
+run-to-run determinism of the forward) plus an exact oracle comparison on one 48-row band of the same
+frame.  Configs 2 and 3 are small enough for a direct oracle comparison at full size."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT, rel_linf, scenes, to_numpy_args
+
+pytestmark = pytest.mark.gpu
+
+GRADS = ["verts", "verts_color", "faces_opacity", "verts_ndc", "faces_intense", "aa_face_verts"]
+
+
+def _C():
+    from dmesh2_renderer_amd import _C as c
+    return c
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _band(args, y0, rows):
+    a = list(args)
+    pm = a[1].clone(); pm[:, 1] += y0
+    a[1] = pm; a[3] = rows
+    a[19] = a[19][:, y0:y0 + rows].contiguous(); a[20] = a[20][:, y0:y0 + rows].contiguous()
+    return a
+
+
+def _fwd_bwd(args, dLc, dLd):
+    C = _C()
+    out = C.render_forward_cuda(*args)
+    g = C.render_backward_cuda(out[0], *args, dLc, dLd, out[7], out[8], out[9], out[3], out[4], out[5], out[6])
+    return out, g
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    b = _bench()
+    args, dLc, dLd, (W, H, F) = b.build_inputs("cfg4", torch.device("cuda", 0), 0, 1)
+    out, g = _fwd_bwd(args, dLc, dLd)
+    torch.cuda.synchronize()
+    return dict(args=args, dLc=dLc, dLd=dLd, W=W, H=H, F=F, out=out, g=[x.clone() for x in g])
+
+
+def test_cfg4_statistics(cfg4):
+    R = cfg4["out"][0]
+    assert 1.4e6 < R < 1.8e6                                    # R ~ 1.59 M at 1080p / 1 M triangles
+    color, depth = cfg4["out"][1], cfg4["out"][2]
+    assert torch.isfinite(color).all() and torch.isfinite(depth).all()
+    assert 0.0 <= float(color.min()) and float(color.max()) <= 1.0 + 1e-4
+    for g in cfg4["g"]:
+        assert torch.isfinite(g).all()
+    assert float(cfg4["g"][1].abs().sum()) > 0
+
+
+def test_cfg4_forward_is_deterministic(cfg4):
+    out2 = _C().render_forward_cuda(*cfg4["args"])
+    assert out2[0] == cfg4["out"][0]
+    assert torch.equal(out2[1], cfg4["out"][1]) and torch.equal(out2[2], cfg4["out"][2]) and torch.equal(out2[5], cfg4["out"][5])
+
+
+def test_cfg4_band_decomposition_equals_full_frame(cfg4):
+    """Tile-row bands (the multi-GPU sharding) reproduce the frame exactly; band gradients add up to the full ones."""
+    from dmesh2_renderer_amd.sharding import all_bands
+    H = cfg4["H"]
+    gsum = [torch.zeros_like(x) for x in cfg4["g"]]
+    for (y0, rows) in all_bands(H, 3):
+        a = _band(cfg4["args"], y0, rows)
+        out, g = _fwd_bwd(a, cfg4["dLc"][:, y0:y0 + rows].contiguous(), cfg4["dLd"][:, y0:y0 + rows].contiguous())
+        assert torch.equal(out[1], cfg4["out"][1][:, y0:y0 + rows])
+        assert torch.equal(out[2], cfg4["out"][2][:, y0:y0 + rows])
+        for s, x in zip(gsum, g):
+            s += x
+    for name, s, ref in zip(GRADS, gsum, cfg4["g"]):
+        err = float((s - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        assert err <= 1e-5, (name, err)
+
+
+def test_cfg4_backward_is_linear_in_upstream_gradient(cfg4):
+    C = _C()
+    out = cfg4["out"]
+    g2 = C.render_backward_cuda(out[0], *cfg4["args"], cfg4["dLc"] * 2.0, cfg4["dLd"] * 2.0, out[7], out[8], out[9],
+                                out[3], out[4], out[5], out[6])
+    for name, a, b in zip(GRADS, g2, cfg4["g"]):
+        err = float((a - 2.0 * b).abs().max() / (2.0 * b).abs().max().clamp_min(1e-12))
+        assert err <= 1e-5, (name, err)
+
+
+def test_cfg4_band_matches_oracle(cfg4):
+    from oracle import cpu as orc
+    y0, rows = 512, 48
+    a = _band(cfg4["args"], y0, rows)
+    dLc = cfg4["dLc"][:, y0:y0 + rows].contiguous(); dLd = cfg4["dLd"][:, y0:y0 + rows].contiguous()
+    out, g = _fwd_bwd(a, dLc, dLd)
+    ref = orc.render_forward_cuda(*to_numpy_args(a), nthreads=orc.max_threads())
+    assert out[0] == ref.num_rendered
+    assert np.array_equal(out[1].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+    assert np.array_equal(out[2].cpu().numpy().view(np.uint32), ref.depth.view(np.uint32))
+    assert np.array_equal(out[5].cpu().numpy(), ref.buf_tri_cnt)
+    gref = orc.render_backward_cuda(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
+    for name, x in zip(GRADS, g):
+        assert rel_linf(x.cpu().numpy(), gref[name]) <= 1e-5, name
+
+
+def test_cfg2_full_size_against_oracle():
+    """BASELINE config 2: forward+backward 512x512, 50k triangles, AA visibility gradients on."""
+    from oracle import cpu as orc
+    b = _bench()
+    args, dLc, dLd, _ = b.build_inputs("cfg2", torch.device("cuda", 0), 0, 1)
+    out, g = _fwd_bwd(args, dLc, dLd)
+    ref = orc.render_forward_cuda(*to_numpy_args(args), nthreads=orc.max_threads())
+    assert out[0] == ref.num_rendered
+    flipped = int((out[5].cpu().numpy() != ref.buf_tri_cnt).sum())
+    assert flipped == 0
+    assert np.array_equal(out[1].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+    assert np.array_equal(out[2].cpu().numpy().view(np.uint32), ref.depth.view(np.uint32))
+    gref = orc.render_backward_cuda(ref, dLc.cpu().numpy(), dLd.cpu().numpy())
+    for name, x in zip(GRADS, g):
+        assert rel_linf(x.cpu().numpy(), gref[name]) <= 1e-5, name
+
+
+def test_cfg3_layered_renderer_full_size():
+    """BASELINE config 3: LayeredRenderer, 4 layers, 1024x1024, 26^3 Kuhn lattice (T = 93 750, F = 191 250)."""
+    from oracle import cpu as orc
+    import dmesh2_renderer_amd as dm2
+    W = H = 1024
+    sc = scenes.tet_lattice(W, H, 25, seed=scenes.SEED_BASE + 3)
+    assert sc.tets.shape[0] == 93750 and sc.faces.shape[0] == 191250
+    scd = sc.to("cuda")
+    lr = dm2.LayeredRenderer(scd.mv, scd.proj, W, H, "cuda")
+    layers, cnt = lr.generate([0], scd.verts, scd.faces, scd.tets, scd.face_tets, scd.tet_faces, scd.faces_existence, 4)
+    ndc, img = lr.compute_verts_ndc_image(scd.verts, scd.mv[[0]], scd.proj[[0]])
+    rl, rc = orc.generate_render_layers_cuda(W, H, sc.verts.numpy(), sc.faces.numpy(), sc.tets.numpy(), sc.face_tets.numpy(),
+                                             sc.tet_faces.numpy(), sc.faces_existence.numpy(), ndc.cpu().numpy(), img.cpu().numpy(),
+                                             lr.ray_o[[0]].cpu().numpy(), lr.ray_d[[0]].cpu().numpy(), 4, nthreads=orc.max_threads())
+    assert np.array_equal(cnt.cpu().numpy(), rc)
+    assert np.array_equal(layers.cpu().numpy(), rl)
+    assert (rc == 4).mean() > 0.3
+
+
+# ---- two ranks on the one GPU, real product path, gloo as the transport ----------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dmesh2_renderer_amd.sharding import BandShardedOp
+        b = _bench()
+        args, dLc, dLd, _ = b.build_inputs("cfg2", torch.device("cuda", 0), rank, world)
+        op = BandShardedOp(args, world, rank)
+        color, depth = op.forward()
+        g = op.backward(dLc[:, op.y0:op.y0 + op.rows].contiguous(), dLd[:, op.y0:op.y0 + op.rows].contiguous())
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), y0=op.y0, rows=op.rows, color=color.cpu().numpy(),
+                 **{f"g{i}": x.cpu().numpy() for i, x in enumerate(g)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_band_sharded_product_path(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.start_processes(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    b = _bench()
+    args, dLc, dLd, _ = b.build_inputs("cfg2", torch.device("cuda", 0), 0, 1)
+    out, g = _fwd_bwd(args, dLc, dLd)
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        y0, rows = int(d["y0"]), int(d["rows"])
+        assert np.array_equal(d["color"], out[1][:, y0:y0 + rows].cpu().numpy())
+        for i, name in enumerate(GRADS):
+            assert rel_linf(d[f"g{i}"], g[i].cpu().numpy()) <= 1e-5, (r, name)

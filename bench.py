@@ -125,12 +125,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product has no CPU path)")
+    # rehearsal knobs (one-GPU boxes): DM2_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, DM2_BENCH_BACKEND=gloo
+    # swaps the transport.  The driver's real runs use neither: one rank per GPU, nccl (= RCCL over xGMI).
+    if os.environ.get("DM2_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DM2_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from dmesh2_renderer_amd import _C
     from dmesh2_renderer_amd.sharding import BandShardedOp

@@ -41,6 +41,18 @@ constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
 struct __attribute__((aligned(16))) BwdPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BwdPair) == 32, "BwdPair");
 
+// DPP row shifts (16-lane rows; lanes shifted in from outside the row read 0)
+template <int N> __device__ __forceinline__ int dpp_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ float dpp_shr_f(float v) { return __int_as_float(dpp_shr_i<N>(__float_as_int(v))); }
+// inclusive segmented sum inside a row of 16 lanes; sK = "lane l-K belongs to the same run"
+__device__ __forceinline__ void seg_scan16(float& v, bool s1, bool s2, bool s4, bool s8) {
+    float t = dpp_shr_f<1>(v); v += s1 ? t : 0.f;
+    t = dpp_shr_f<2>(v); v += s2 ? t : 0.f;
+    t = dpp_shr_f<4>(v); v += s4 ? t : 0.f;
+    t = dpp_shr_f<8>(v); v += s8 ? t : 0.f;
+}
+
 __global__ void __launch_bounds__(TILE_PIX, DM2_BD_WAVES)
 k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -255,32 +267,37 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             STAMP(8)
 
             // ---- phase D: chain rule + per-entry accumulation -------------------------------
+            float gv[B_N];
+#pragma unroll
+            for (int c = 0; c < B_N; c++) gv[c] = 0.f;
+            bool active = false;
             if (have && blend) {
                 const BwdPair pr = s_pair[bi & (BD_NBUF - 1)][tid];
                 if (pr.flags & BF_ACTIVE) {
+                    active = true;
                     const FaceRec& fc = recs[j];
                     const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
                     const float qc0 = s_dL[q * 4], qc1 = s_dL[q * 4 + 1], qc2 = s_dL[q * 4 + 2], qd = s_dL[q * 4 + 3];
                     const float intense = fc.intense, opacity = fc.opacity;
                     const float dics[3] = {qc0 * alpha * Tq, qc1 * alpha * Tq, qc2 * alpha * Tq};
                     const float did = qd * alpha * Tq;
-                    const float dL_dfop = dL_dalpha * ratio;
+                    gv[B_OP] = dL_dalpha * ratio;
                     const float dL_dratio = (dL_dalpha * opacity) * temp;
                     const float dL_doarea = dL_dratio / pix_area;
                     float dL_di0 = 0.f, dL_di1 = 0.f, dL_di2 = 0.f, dL_dfint = 0.f;
-                    float dvc[9];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         dL_di0 += fc.col[ch] * dics[ch] * intense;
                         dL_di1 += fc.col[3 + ch] * dics[ch] * intense;
                         dL_di2 += fc.col[6 + ch] * dics[ch] * intense;
-                        dvc[ch] = 0.f + i0 * dics[ch] * intense;
-                        dvc[3 + ch] = 0.f + i1 * dics[ch] * intense;
-                        dvc[6 + ch] = 0.f + i2 * dics[ch] * intense;
+                        gv[B_DC + ch] = 0.f + i0 * dics[ch] * intense;
+                        gv[B_DC + 3 + ch] = 0.f + i1 * dics[ch] * intense;
+                        gv[B_DC + 6 + ch] = 0.f + i2 * dics[ch] * intense;
                         dL_dfint += (i0 * fc.col[ch] + i1 * fc.col[3 + ch] + i2 * fc.col[6 + ch]) * dics[ch];
                     }
+                    gv[B_IN] = dL_dfint;
                     dL_di0 += fc.dep[0] * did; dL_di1 += fc.dep[1] * did; dL_di2 += fc.dep[2] * did;
-                    const float dvd0 = 0.f + i0 * did, dvd1 = 0.f + i1 * did, dvd2 = 0.f + i2 * did;
+                    gv[B_DZ + 0] = 0.f + i0 * did; gv[B_DZ + 1] = 0.f + i1 * did; gv[B_DZ + 2] = 0.f + i2 * did;
                     float diuc_diu, diuc_div, divc_diu, divc_div;
                     clamp_bary_uv_grad(code, diuc_diu, diuc_div, divc_diu, divc_div);
                     const float di0_diu = -1.f * diuc_diu + -1.f * divc_diu, di0_div = -1.f * diuc_div + -1.f * divc_div;
@@ -296,17 +313,37 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     const f3 dp0 = dL_diu * du0 + dL_div * dv0;
                     const f3 dp1 = dL_diu * du1 + dL_div * dv1;
                     const f3 dp2 = dL_diu * du2 + dL_div * dv2;
+                    gv[B_DV + 0] = dp0.x; gv[B_DV + 1] = dp0.y; gv[B_DV + 2] = dp0.z;
+                    gv[B_DV + 3] = dp1.x; gv[B_DV + 4] = dp1.y; gv[B_DV + 5] = dp1.z;
+                    gv[B_DV + 6] = dp2.x; gv[B_DV + 7] = dp2.y; gv[B_DV + 8] = dp2.z;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) gv[B_AA + c] = dL_doarea * dg[c];
+                }
+            }
+            // Pairs are face-major, so the lanes of one face are neighbours.  Sum the 29 partials over the run of
+            // equal faces inside each row of 16 lanes with DPP shifts (pure VALU), then only the last lane of each
+            // run touches LDS: ~8 instead of up to 64 lane-atomics per ds_add_f32 (the LDS atomic unit was the
+            // bottleneck of this phase).
+            {
+                const int jkey = have ? j : -1;
+                const int l16 = tid & 15;
+                // NB: every DPP read must execute with all lanes enabled (a lane disabled by a short-circuit
+                // `&&` reads as 0 for its neighbours), hence the unconditional reads first and `&`, `|` below.
+                const int k1 = dpp_shr_i<1>(jkey), k2 = dpp_shr_i<2>(jkey), k4 = dpp_shr_i<4>(jkey), k8 = dpp_shr_i<8>(jkey);
+                const int kn = dpp_shl_i<1>(jkey);
+                const bool s1 = (l16 >= 1) & (k1 == jkey);
+                const bool s2 = (l16 >= 2) & (k2 == jkey);
+                const bool s4 = (l16 >= 4) & (k4 == jkey);
+                const bool s8 = (l16 >= 8) & (k8 == jkey);
+                float nact = active ? 1.f : 0.f;
+                seg_scan16(nact, s1, s2, s4, s8);
+#pragma unroll
+                for (int c = 0; c < B_N; c++) seg_scan16(gv[c], s1, s2, s4, s8);
+                const bool run_end = (l16 == 15) | (kn != jkey);
+                if (run_end && jkey >= 0 && nact > 0.f) {
                     float* a = acc + j * BD_ACC;
-                    atomicAdd(a + B_DV + 0, dp0.x); atomicAdd(a + B_DV + 1, dp0.y); atomicAdd(a + B_DV + 2, dp0.z);
-                    atomicAdd(a + B_DV + 3, dp1.x); atomicAdd(a + B_DV + 4, dp1.y); atomicAdd(a + B_DV + 5, dp1.z);
-                    atomicAdd(a + B_DV + 6, dp2.x); atomicAdd(a + B_DV + 7, dp2.y); atomicAdd(a + B_DV + 8, dp2.z);
 #pragma unroll
-                    for (int c = 0; c < 9; c++) atomicAdd(a + B_DC + c, dvc[c]);
-                    atomicAdd(a + B_DZ + 0, dvd0); atomicAdd(a + B_DZ + 1, dvd1); atomicAdd(a + B_DZ + 2, dvd2);
-                    atomicAdd(a + B_OP, dL_dfop);
-                    atomicAdd(a + B_IN, dL_dfint);
-#pragma unroll
-                    for (int c = 0; c < 6; c++) atomicAdd(a + B_AA + c, dL_doarea * dg[c]);
+                    for (int c = 0; c < B_N; c++) atomicAdd(a + c, gv[c]);
                     a[B_FLAG] = 1.0f;
                 }
             }

@@ -65,6 +65,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ float s_dL[TILE_PIX * 4];
     __shared__ int s_off[BD_CHUNK + 1];
+    __shared__ int s_jlo[BD_CHUNK + 1];                        // first face of every 256-pair batch of the chunk
     __shared__ uint32_t s_rect[BD_CHUNK];
     __shared__ int s_wave[4];
     __shared__ int s_inv[17];
@@ -142,11 +143,11 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
         for (int k = tid; k < n * BD_ACC; k += TILE_PIX) acc[k] = 0.f;
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        if (tid < n) s_off[tid] = ex;
-        if (tid == n) s_off[n] = tot;
+        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+        if (tid < n) { s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt); }
+        if (tid == n) { s_off[n] = tot; s_jlo[nb] = n; }
         __syncthreads();
         STAMP(3)
-        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
 
         for (int bi = 0; bi < nb; bi++) {
             // ---- phase B ------------------------------------------------------------------
@@ -158,7 +159,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             int code = 0;
             bool blend = false;
             if (have) {
-                j = find_face(s_off, n, k);
+                j = find_face_in(s_off, s_jlo[bi], min(s_jlo[bi + 1] + 1, n), k);
                 const uint32_t rect = s_rect[j];
                 int qx, qy;
                 pair_xy(rect, k - s_off[j], s_inv, qx, qy);
@@ -203,7 +204,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 }
                 s_pair[bi & (BD_NBUF - 1)][tid] = out;
                 if (blend) {
-                    const int bit = j - find_face(s_off, n, bi * TILE_PIX);
+                    const int bit = j - s_jlo[bi];
                     if (bit < 64) atomicOr(&s_mask[bi & (BD_NBUF - 1)][q], 1ull << bit);
                     else s_ovf[bi & (BD_NBUF - 1)][q] = 1;
                 }
@@ -219,7 +220,7 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 s_mask[bi & (BD_NBUF - 1)][tid] = 0;
                 const bool ovf = s_ovf[bi & (BD_NBUF - 1)][tid] != 0;
                 s_ovf[bi & (BD_NBUF - 1)][tid] = 0;
-                const int jlo = find_face(s_off, n, k0);
+                const int jlo = s_jlo[bi];
                 const int jhi = ovf ? find_face(s_off, n, k1 - 1) : jlo;
                 int jover = jlo + 64;
                 // faces flagged in the mask first (ascending = back to front), then any beyond the 64 mask bits

@@ -35,6 +35,7 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ FwdPair s_pair[2][TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ int s_off[FD_CHUNK + 1];
+    __shared__ int s_jlo[FD_CHUNK + 1];                  // first face of every 256-pair batch of the chunk
     __shared__ uint32_t s_rect[FD_CHUNK];
     __shared__ int s_wave[4];
     __shared__ int s_inv[17];
@@ -96,18 +97,18 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(2)
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        if (tid < n) s_off[tid] = ex;
-        if (tid == n) s_off[n] = tot;
+        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+        if (tid < n) { s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt); }
+        if (tid == n) { s_off[n] = tot; s_jlo[nb] = n; }
         __syncthreads();
         STAMP(3)
-        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
 
         // ---- phase B: one pair per lane ------------------------------------------------
         auto eval_batch = [&](int bi) {
             const int k = bi * TILE_PIX + tid;
             if (k >= tot) return;
-            const int jlo_b = find_face(s_off, n, bi * TILE_PIX);      // first face of this batch (block uniform)
-            const int j = find_face(s_off, n, k);
+            const int jlo_b = s_jlo[bi];                               // first face of this batch (block uniform)
+            const int j = find_face_in(s_off, jlo_b, min(s_jlo[bi + 1] + 1, n), k);
             const uint32_t rect = s_rect[j];
             int qx, qy;
             pair_xy(rect, k - s_off[j], s_inv, qx, qy);
@@ -172,7 +173,7 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 s_mask[bi & 1][tid] = 0;                                   // ready for batch bi+2
                 const bool ovf = s_ovf[bi & 1][tid] != 0;
                 s_ovf[bi & 1][tid] = 0;
-                const int jlo = find_face(s_off, n, k0);
+                const int jlo = s_jlo[bi];
                 auto blend_face = [&](int j) -> bool {                    // returns true when the pixel terminates
                     const int o = s_off[j];
                     if (s_off[j + 1] == o) return false;

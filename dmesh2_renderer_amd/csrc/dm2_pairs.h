@@ -66,13 +66,20 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave, int& tot
 }
 
 // Face index of pair k: largest j with off[j] <= k (off is the exclusive scan, off[n] = total).
-__device__ __forceinline__ int find_face(const int* off, int n, int k) {
-    int lo = 0, hi = n;          // invariant: off[lo] <= k < off[hi]
-    while (hi - lo > 1) {
+__device__ __forceinline__ int find_face_in(const int* off, int lo, int hi, int k) {
+    while (hi - lo > 1) {        // invariant: off[lo] <= k < off[hi]
         const int mid = (lo + hi) >> 1;
         if (off[mid] <= k) lo = mid; else hi = mid;
     }
     return lo;
+}
+__device__ __forceinline__ int find_face(const int* off, int n, int k) { return find_face_in(off, 0, n, k); }
+
+// First face of every 256-pair batch, written by the face's own staging lane (ex = its exclusive
+// prefix, cnt = its pair count): face j holds pairs [ex, ex+cnt), so it is find_face(b*256) for the
+// batch boundaries inside that interval.  jlo[nb] = n closes the table.
+__device__ __forceinline__ void note_batch_starts(int* jlo, int j, int ex, int cnt) {
+    for (int b = (ex + 255) >> 8; (b << 8) < ex + cnt; b++) jlo[b] = j;
 }
 
 // local pair index -> (dx, dy) inside a rectangle of width w <= 16 (local < 256)

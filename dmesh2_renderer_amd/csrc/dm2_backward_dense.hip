@@ -127,10 +127,12 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
 
     STAMP(0)
-    for (int base = 0; base < total; base += BD_CHUNK) {
+    int n = 0;
+    for (int base = 0; base < total; base += n) {
         __syncthreads();                                            // previous chunk flushed, LDS reusable
         STAMP(1)
-        const int n = min(BD_CHUNK, total - base);
+        n = min(BD_CHUNK, total - base);
+        const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
             // recs[j] = entry (total-1) - (base+j): back to front (backward.cu:171)
@@ -143,10 +145,11 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
         for (int k = tid; k < n * BD_ACC; k += TILE_PIX) acc[k] = 0.f;
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+        int nb = (tot + TILE_PIX - 1) / TILE_PIX;
         if (tid < n) { s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt); }
         if (tid == n) { s_off[n] = tot; s_jlo[nb] = n; }
         __syncthreads();
+        cut_to_full_batches(s_off, s_jlo, last_chunk, n, tot, nb);
         STAMP(3)
 
         for (int bi = 0; bi < nb; bi++) {
@@ -225,16 +228,19 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 int jover = jlo + 64;
                 // faces flagged in the mask first (ascending = back to front), then any beyond the 64 mask bits
                 while (m || (ovf && jover <= jhi)) {
+                    // (deriving the slot straight from the mask bit, as the forward does, costs registers here:
+                    // 3.07 ms instead of 2.91 ms at cfg4 -- this kernel sits on its 168-VGPR budget)
                     int jj;
                     if (m) { jj = jlo + __ffsll((long long)m) - 1; m &= m - 1; }
                     else jj = jover++;
-                    const uint32_t e = (uint32_t)(total - 1 - base - jj);        // 0-based position in the list
-                    if (e >= last_contributor) continue;                          // backward.cu:219-221
                     const int o = s_off[jj];
                     if (s_off[jj + 1] == o) continue;
                     const int kk = pixel_pair(s_rect[jj], o, lx, ly);
                     if (kk < k0 || kk >= k1) continue;
-                    BwdPair& pr = s_pair[bi & (BD_NBUF - 1)][kk - k0];
+                    const int kidx = kk - k0;
+                    const uint32_t e = (uint32_t)(total - 1 - base - jj);        // 0-based position in the list
+                    if (e >= last_contributor) continue;                          // backward.cu:219-221
+                    BwdPair& pr = s_pair[bi & (BD_NBUF - 1)][kidx];
                     if (!(pr.flags & BF_BLEND)) continue;
                     const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
                     if (!T_first_pass) T = T / (1.f - a);                         // backward.cu:340-348

@@ -37,6 +37,7 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ int s_off[FD_CHUNK + 1];
     __shared__ int s_jlo[FD_CHUNK + 1];                  // first face of every 256-pair batch of the chunk
     __shared__ uint32_t s_rect[FD_CHUNK];
+    __shared__ int s_kb[FD_CHUNK];                       // pair index of the face's (virtual) tile pixel (0,0): off - y0*w - x0
     __shared__ int s_wave[4];
     __shared__ int s_inv[17];
     __shared__ unsigned long long s_mask[2][TILE_PIX];   // per pixel: faces of the current batch that produced a pair for it
@@ -83,10 +84,12 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     int rec_cnt = 0;
 
     STAMP(0)
-    for (int base = 0; base < total; base += FD_CHUNK) {
+    int n = 0;
+    for (int base = 0; base < total; base += n) {
         if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260; also fences LDS reuse
         STAMP(1)
-        const int n = min(FD_CHUNK, total - base);
+        n = min(FD_CHUNK, total - base);
+        const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
             stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
@@ -97,10 +100,15 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(2)
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        const int nb = (tot + TILE_PIX - 1) / TILE_PIX;
-        if (tid < n) { s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt); }
+        int nb = (tot + TILE_PIX - 1) / TILE_PIX;
+        if (tid < n) {
+            s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt);
+            const uint32_t r = s_rect[tid];
+            s_kb[tid] = ex - (int)((r >> 4) & 15u) * ((int)((r >> 8) & 15u) + 1) - (int)(r & 15u);
+        }
         if (tid == n) { s_off[n] = tot; s_jlo[nb] = n; }
         __syncthreads();
+        cut_to_full_batches(s_off, s_jlo, last_chunk, n, tot, nb);
         STAMP(3)
 
         // ---- phase B: one pair per lane ------------------------------------------------
@@ -174,12 +182,8 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 const bool ovf = s_ovf[bi & 1][tid] != 0;
                 s_ovf[bi & 1][tid] = 0;
                 const int jlo = s_jlo[bi];
-                auto blend_face = [&](int j) -> bool {                    // returns true when the pixel terminates
-                    const int o = s_off[j];
-                    if (s_off[j + 1] == o) return false;
-                    const int k = pixel_pair(s_rect[j], o, lx, ly);
-                    if (k < k0 || k >= k1) return false;
-                    const FwdPair pr = s_pair[bi & 1][k - k0];
+                auto blend_pair = [&](int kk, int j) -> bool {            // returns true when the pixel terminates
+                    const FwdPair pr = s_pair[bi & 1][kk];
                     if ((pr.flags & PF_REC) && rec_cnt < K) rec_cnt++;       // forward.cu:344-352
                     if (!(pr.flags & PF_BLEND)) return false;
                     const float alpha = pr.alpha;
@@ -190,15 +194,24 @@ k_render_forward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     last_contributor = (uint32_t)(base + j + 1);
                     return T < T_EPS;
                 };
+                // a mask bit is only ever set by a pair of this batch that covers this pixel, so the pair's
+                // slot follows from the face's row pitch without any rectangle or range test
+                const int lin = lx - k0;
                 while (m && !done) {
-                    const int bit = __ffsll((long long)m) - 1;
+                    const int j = jlo + __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    if (blend_face(jlo + bit)) done = true;
+                    const int w = (int)((s_rect[j] >> 8) & 15u) + 1;
+                    if (blend_pair(s_kb[j] + ly * w + lin, j)) done = true;
                 }
                 if (ovf) {                                                 // > 64 faces in one batch: plain walk of the rest
                     const int jhi = find_face(s_off, n, k1 - 1);
-                    for (int j = jlo + 64; j <= jhi && !done; j++)
-                        if (blend_face(j)) done = true;
+                    for (int j = jlo + 64; j <= jhi && !done; j++) {
+                        const int o = s_off[j];
+                        if (s_off[j + 1] == o) continue;
+                        const int k = pixel_pair(s_rect[j], o, lx, ly);
+                        if (k < k0 || k >= k1) continue;
+                        if (blend_pair(k - k0, j)) done = true;
+                    }
                 }
             }
             STAMP(6)

@@ -100,15 +100,14 @@ __device__ __forceinline__ void clip_edge_area(const AAFace& f, float pxmin, flo
     }
 }
 
-// aa.h:446-504, area only.  Returns non-zero on any reference error; area valid when 0.
-__device__ __forceinline__ int tri_pix_overlap_area_only(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
-                                                         float pix_area, float& area) {
-    area = 0.f;
-    if ((pxmax < f.bb[0]) || (pxmin > f.bb[1]) || (pymax < f.bb[2]) || (pymin > f.bb[3])) return 0;   // aa.h:96-101
-    uint32_t inside = 0xF;
+// aa.h:103-149: per pixel corner, is it inside all three half planes (bit i of `inside`, corners in the
+// order (xmin,ymin) (xmax,ymin) (xmax,ymax) (xmin,ymax)).  Returns false when some edge has all four
+// corners on its outer side -- the reference then reports area 0.
+__device__ __forceinline__ bool classify_pixel(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax, uint32_t& inside) {
+    inside = 0xF;
     bool outside = false;
 #pragma unroll
-    for (int ti = 0; ti < 3; ti++) {                                                                    // aa.h:103-149
+    for (int ti = 0; ti < 3; ti++) {
         const float nx = f.n[2 * ti], ny = f.n[2 * ti + 1], c = f.c[ti];
         const bool i0 = (pxmin * nx) + (pymin * ny) - c >= 0;
         const bool i1 = (pxmax * nx) + (pymin * ny) - c >= 0;
@@ -117,7 +116,13 @@ __device__ __forceinline__ int tri_pix_overlap_area_only(const AAFace& f, float 
         outside = outside || !(i0 || i1 || i2 || i3);
         inside &= (uint32_t)i0 | ((uint32_t)i1 << 1) | ((uint32_t)i2 << 2) | ((uint32_t)i3 << 3);
     }
-    if (outside) return 0;
+    return !outside;
+}
+
+// aa.h:151-441 for a pixel that passed classify_pixel.  Returns non-zero on any reference error.
+__device__ __forceinline__ int clip_area_classified(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                                    uint32_t inside, float pix_area, float& area) {
+    area = 0.f;
     if (inside == 0xF) { area = pix_area; return 0; }
 #ifdef DM2_ABLATE_CLIP   // diagnostic only: price of the polygon clip
     area = 0.5f * pix_area; return 0;
@@ -131,6 +136,16 @@ __device__ __forceinline__ int tri_pix_overlap_area_only(const AAFace& f, float 
     if (S.area > pix_area) return 6;                                                                    // E05
     area = S.area;
     return 0;
+}
+
+// aa.h:446-504, area only.  Returns non-zero on any reference error; area valid when 0.
+__device__ __forceinline__ int tri_pix_overlap_area_only(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                                         float pix_area, float& area) {
+    area = 0.f;
+    if ((pxmax < f.bb[0]) || (pxmin > f.bb[1]) || (pymax < f.bb[2]) || (pymin > f.bb[3])) return 0;   // aa.h:96-101
+    uint32_t inside;
+    if (!classify_pixel(f, pxmin, pxmax, pymin, pymax, inside)) return 0;
+    return clip_area_classified(f, pxmin, pxmax, pymin, pymax, inside, pix_area, area);
 }
 
 }  // namespace dm2

@@ -1,0 +1,273 @@
+// dm2_forward_queue.hip -- forward composite, dense pairs with survivor compaction.
+//
+// Same results as k_render_forward (dm2_forward.hip; FORWARD::renderCUDA<3>,
+// forward.cu:139-432).  Work distribution (see dm2_pairs.h for the pair enumeration):
+//
+//   A   stage a chunk of faces, exact pixel rectangle per face, block scan -> pair index k
+//   B1  one pair per lane: the corner / half-plane classification only (aa.h:103-149).
+//       About a third of the rectangle pairs are rejected here; the survivors are
+//       compacted, in pair order, into an LDS queue (wave ballot + prefix count, every
+//       wave owns a contiguous quarter of the chunk's pairs so the order is global).
+//   B2  one SURVIVOR per lane: polygon clip, Moeller-Trumbore, barycentric clamp, coverage
+//       mix, interpolated colour / depth -> pair record in LDS.  All lanes carry work.
+//   C   every pixel blends its own records in list order (64-bit face mask per pixel).
+//
+// The chunk is cut twice at a face boundary: to PAIRCAP pairs before B1 and to SURVCAP
+// survivors after it; faces beyond a cut are staged again by the next chunk.
+#include <hip/hip_runtime.h>
+
+#include "dm2_clip_area.h"
+#include "dm2_device_math.h"
+#include "dm2_pairs.h"
+#include "dm2_stage.h"
+#include "dm2_stamps.h"
+#include "dm2_state.h"
+
+namespace dm2 {
+
+#ifndef DM2_FQ_CHUNK
+#define DM2_FQ_CHUNK 52
+#endif
+#ifndef DM2_FQ_PAIRCAP
+#define DM2_FQ_PAIRCAP 768
+#endif
+#ifndef DM2_FQ_SURVCAP
+#define DM2_FQ_SURVCAP 512
+#endif
+constexpr int FQ_CHUNK = DM2_FQ_CHUNK;
+constexpr int FQ_PAIRCAP = DM2_FQ_PAIRCAP;
+constexpr int FQ_SURVCAP = DM2_FQ_SURVCAP;
+constexpr int FQ_QCAP = ((FQ_PAIRCAP + 3) / 4 + 63) & ~63;     // queue region of one wave
+static_assert(FQ_CHUNK <= 64, "one mask bit per staged face");
+static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
+static_assert(FQ_PAIRCAP < 65536, "16-bit slots");
+
+constexpr uint32_t QF_REC = 1u;      // AA overlap found (the reference takes an AA record here)
+constexpr uint32_t QF_BLEND = 2u;    // the face blends into the pixel
+
+struct __attribute__((aligned(8))) FqPair { float alpha, c0, c1, c2, depth; uint32_t flags; };
+
+__global__ void __launch_bounds__(TILE_PIX, 4)
+k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
+                       ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
+                       int32_t* __restrict__ out_tri_cnt STAMP_PARAM) {
+    __shared__ FaceRec recs[FQ_CHUNK];
+    __shared__ FqPair s_pair[FQ_SURVCAP];
+    __shared__ float s_ray[TILE_PIX * 6];
+    __shared__ int s_off[FQ_CHUNK + 1];
+    __shared__ uint32_t s_rect[FQ_CHUNK];
+    __shared__ int s_kb[FQ_CHUNK];                       // pair index of the face's (virtual) tile pixel (0,0): off - y0*w - x0
+    __shared__ int s_wave[4];
+    __shared__ int s_wtot[4];                            // survivors per wave
+    __shared__ int s_inv[17];
+    __shared__ uint16_t s_slot[FQ_PAIRCAP];              // per pair: survivors before it within its wave's range
+    __shared__ uint32_t s_queue[4 * FQ_QCAP];            // survivors: q | face << 8 | corner mask << 14
+    __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
+
+    const int b = blockIdx.z;
+    const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    STAMP_DECL
+    fill_inv_table(s_inv);
+    s_mask[tid] = 0;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const uint32_t px = X0 + lx, py = Y0 + ly;
+    const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
+    const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
+    const uint32_t pmx = (uint32_t)d.patch_min[2 * b], pmy = (uint32_t)d.patch_min[2 * b + 1];
+    const int X0a = X0 + (int)pmx, Y0a = Y0 + (int)pmy;
+    const int xlim = min(TILE - 1, d.W - 1 - X0), ylim = min(TILE - 1, d.H - 1 - Y0);
+
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s_ray[tid * 6 + k] = d.image_ray_o[3 * pix + k];
+            s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
+        }
+    }
+    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const float temp = d.aa_temperature;
+    const bool use_aa = temp > 0.0f;
+    const float pix_area = 1.0f;
+    const int K = d.K;
+
+    bool done = !inside;
+    float pT = 1.0f, T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    int rec_cnt = 0;
+
+    STAMP(0)
+    int n = 0;
+    for (int base = 0; base < total; base += n) {
+        if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260; also fences LDS reuse
+        STAMP(1)
+        // ---- phase A ----------------------------------------------------------------------
+        n = min(FQ_CHUNK, total - base);
+        int cnt = 0;
+        if (tid < n) {
+            stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
+            uint32_t rect;
+            cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
+            s_rect[tid] = rect;
+        }
+        STAMP(2)
+        int tot;
+        const int ex = block_exclusive_scan(cnt, s_wave, tot);
+        if (tid < n) {
+            s_off[tid] = ex;
+            const uint32_t r = s_rect[tid];
+            s_kb[tid] = ex - (int)((r >> 4) & 15u) * ((int)((r >> 8) & 15u) + 1) - (int)(r & 15u);
+        }
+        if (tid == n) s_off[n] = tot;
+        __syncthreads();
+        if (tot > FQ_PAIRCAP) {                                     // cut 1: faces [0, n) hold at most PAIRCAP pairs
+            n = find_face(s_off, n, FQ_PAIRCAP);                    // >= 1: a face owns at most 256 pairs
+            tot = s_off[n];
+        }
+        STAMP(3)
+
+        // ---- phase B1: classify, compact survivors in pair order ---------------------------
+        const int Q = (((tot + 3) >> 2) + 63) & ~63;               // pairs per wave, whole rounds of 64
+        int wcount = 0;
+        for (int r = 0; r < Q; r += 64) {
+            const int k = wid * Q + r + lane;
+            bool surv = false;
+            uint32_t entry = 0;
+            if (k < tot) {
+                const int j = find_face(s_off, n, k);
+                int qx, qy;
+                pair_xy(s_rect[j], k - s_off[j], s_inv, qx, qy);
+                uint32_t cmask = 0xF;
+                surv = true;
+                if (use_aa) {
+                    const float pxmin = (float)(uint32_t)(X0a + qx), pymin = (float)(uint32_t)(Y0a + qy);
+                    // (the rectangle already is the exact set of pixels that pass the bbox test, aa.h:96-101)
+                    surv = classify_pixel(recs[j].aa, pxmin, pxmin + 1, pymin, pymin + 1, cmask);
+                }
+                entry = (uint32_t)(qy * TILE + qx) | ((uint32_t)j << 8) | (cmask << 14);
+            }
+            const unsigned long long bal = __ballot(surv);
+            const int before = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (k < tot) s_slot[k] = (uint16_t)before;
+            if (surv) s_queue[wid * FQ_QCAP + before] = entry;
+            wcount += __popcll(bal);
+        }
+        if (lane == 0) s_wtot[wid] = wcount;
+        __syncthreads();
+        STAMP(4)
+        const int wb1 = s_wtot[0], wb2 = wb1 + s_wtot[1], wb3 = wb2 + s_wtot[2];
+        int S = wb3 + s_wtot[3];
+        // global survivor prefix at pair k (k <= tot)
+        auto surv_before = [&](int k) -> int {
+            if (k >= tot) return S;
+            const int w = (k >= Q) + (k >= 2 * Q) + (k >= 3 * Q);
+            return (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3))) + (int)s_slot[k];
+        };
+        if (S > FQ_SURVCAP) {                                       // cut 2: largest face prefix with <= SURVCAP survivors
+            int lo = 1, hi = n;                                     // surv_before(off[1]) <= 256 holds, surv_before(off[n]) = S does not
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (surv_before(s_off[mid]) <= FQ_SURVCAP) lo = mid; else hi = mid;
+            }
+            const int S2 = surv_before(s_off[lo]);
+            n = lo; tot = s_off[lo]; S = S2;
+        }
+
+        // ---- phase B2: one survivor per lane ------------------------------------------------
+        for (int s = tid; s < S; s += TILE_PIX) {
+            const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
+            const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
+            const uint32_t entry = s_queue[w * FQ_QCAP + (s - wb)];
+            const int q = (int)(entry & 255u), j = (int)((entry >> 8) & 63u);
+            const uint32_t cmask = entry >> 14;
+            const FaceRec& fc = recs[j];
+            const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pxmax = pxmin + 1;
+            const float pymin = (float)(uint32_t)(Y0a + (q >> 4)), pymax = pymin + 1;
+            FqPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0;
+            float oarea = 0.f;
+            bool live = true;
+            if (use_aa) {
+                const int err = clip_area_classified(fc.aa, pxmin, pxmax, pymin, pymax, cmask, pix_area, oarea);
+                live = !((err != 0) || (oarea == 0.0f));
+                if (live) out.flags |= QF_REC;
+            }
+            if (live) {
+                float ratio = oarea / pix_area;
+                const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
+                const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
+                const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                f3 tuv = {0, 0, 0};
+                if (ray_tri_intersection(ro, rd, p0, p1, p2, tuv)) {
+                    float iuc, ivc; int code;
+                    clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
+                    const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+                    ratio = mix_coverage(code, ratio, temp);
+                    if (ratio != 0.0f) {
+                        float c0 = i0 * fc.col[0] + i1 * fc.col[3] + i2 * fc.col[6];
+                        float c1 = i0 * fc.col[1] + i1 * fc.col[4] + i2 * fc.col[7];
+                        float c2 = i0 * fc.col[2] + i1 * fc.col[5] + i2 * fc.col[8];
+                        out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
+                        out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
+                        out.alpha = fc.opacity * ratio;
+                        out.flags |= QF_BLEND;
+                    }
+                }
+            }
+            if (out.flags) {
+                s_pair[s] = out;
+                atomicOr(&s_mask[q], 1ull << j);
+            }
+        }
+        STAMP(5)
+        __syncthreads();
+
+        // ---- phase C: ordered blend of this pixel's records ---------------------------------
+        {
+            unsigned long long m = s_mask[tid];
+            s_mask[tid] = 0;
+            while (m && !done) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                // a mask bit is only set by a record for this pixel, so its pair index follows from the row pitch
+                const int k = s_kb[j] + ly * ((int)((s_rect[j] >> 8) & 15u) + 1) + lx;
+                const FqPair pr = s_pair[surv_before(k)];
+                if ((pr.flags & QF_REC) && rec_cnt < K) rec_cnt++;           // forward.cu:344-352
+                if (!(pr.flags & QF_BLEND)) continue;
+                const float alpha = pr.alpha;
+                const float test_T = T * (1 - alpha);
+                C0 += pr.c0 * alpha * T; C1 += pr.c1 * alpha * T; C2 += pr.c2 * alpha * T;
+                D += pr.depth * alpha * T;
+                pT = T; T = test_T;
+                last_contributor = (uint32_t)(base + j + 1);
+                if (T < T_EPS) done = true;
+            }
+        }
+        STAMP(6)
+    }
+
+    if (inside) {
+        is.final_prev_T[pix] = pT;
+        is.final_T[pix] = T;
+        is.n_contrib[pix] = last_contributor;
+        out_color[3 * pix] = C0 + T * d.background[0];
+        out_color[3 * pix + 1] = C1 + T * d.background[1];
+        out_color[3 * pix + 2] = C2 + T * d.background[2];
+        out_depth[pix] = D + T * 1.0f;
+        if (out_tri_cnt) out_tri_cnt[pix] = rec_cnt;
+    }
+    STAMP(7)
+    STAMP_FLUSH
+}
+
+void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
+    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    StageTimer tm(ST_FWD, st);
+    hipLaunchKernelGGL(k_render_forward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt STAMP_ARG(0));
+}
+
+}  // namespace dm2

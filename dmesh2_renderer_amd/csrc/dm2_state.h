@@ -106,6 +106,8 @@ void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_dep
 
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                            float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
+void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
 void launch_render_forward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
 void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,

@@ -226,7 +226,7 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                             float* dL_daa_face_verts, hipStream_t st) {
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
-        launch_render_backward_dense(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+        launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
                                      dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
         return;
     }

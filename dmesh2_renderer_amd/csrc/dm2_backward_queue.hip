@@ -1,20 +1,25 @@
-// dm2_backward_dense.hip -- backward composite, dense (pixel,face)-pair formulation.
+// dm2_backward_queue.hip -- backward composite, dense pairs with survivor compaction.
 //
 // Same results as k_render_backward (dm2_backward.hip; BACKWARD::renderCUDA<3>,
 // backward.cu:17-532) up to fp32 summation order of the scattered gradients.
-// Per chunk of staged faces (walked back to front) and per batch of 256 pairs:
-//   B  lane k: recompute AA area + Jacobian, Moeller-Trumbore, clamp, coverage,
-//      alpha, interpolated colour/depth of pair k  -> small record in LDS;
-//      the Jacobian / barycentrics stay in registers.
-//   C  pixel p: replay its pairs of the batch back to front (transmittance
-//      recovery, dL/dalpha recurrence, backward.cu:340-405) -> T, dL/dalpha into the record.
-//   D  lane k: chain rule for pair k (backward.cu:408-488) and 29 ds_add_f32 into the
-//      per-(tile,entry) accumulators; flushed per chunk with (entry,component) atomics.
+// Per chunk of staged faces (walked back to front):
+//   A   stage, exact pixel rectangle per face, block scan -> pair index k
+//   B1  one pair per lane: corner / half-plane classification only (aa.h:103-149);
+//       survivors compacted in pair order into an LDS queue (as dm2_forward_queue.hip)
+// then per round of 256 survivors:
+//   B2  lane s: AA area + Jacobian, Moeller-Trumbore, clamp, coverage, alpha, interpolated
+//       colour / depth of survivor s -> small record in LDS; Jacobian / barycentrics stay
+//       in registers
+//   C   pixel p: replay its records of the round back to front (transmittance recovery,
+//       dL/dalpha recurrence, backward.cu:340-405) -> T, dL/dalpha into the record
+//   D   lane s: chain rule (backward.cu:408-488), DPP pre-reduction over the lanes of one
+//       face, ds_add_f32 into the per-(tile,entry) accumulators
+// and per chunk a flush with (entry,component) global atomics.
 #include <hip/hip_runtime.h>
 
 #include "dm2_clip_grad.h"
-#include "dm2_clip_lds.h"
 #include "dm2_device_math.h"
+#include "dm2_dpp.h"
 #include "dm2_pairs.h"
 #include "dm2_stage.h"
 #include "dm2_stamps.h"
@@ -22,66 +27,57 @@
 
 namespace dm2 {
 
-#ifndef DM2_BD_CHUNK
-#define DM2_BD_CHUNK 28   // with NBUF 1 the block needs 53.5 KB LDS / <=168 VGPRs -> 3 blocks per CU.  A/B at cfg4 on MI355X:
-                          // chunk 64 / 2 buffers (2 blocks/CU) 6.37 ms, chunk 32 / 2 buffers 6.68 ms, chunk 28 / 1 buffer / 3 blocks 5.64 ms
+#ifndef DM2_BQ_CHUNK
+#define DM2_BQ_CHUNK 28
 #endif
-constexpr int BD_CHUNK = DM2_BD_CHUNK;
-#ifndef DM2_BD_NBUF
-#define DM2_BD_NBUF 1
+#ifndef DM2_BQ_PAIRCAP
+#define DM2_BQ_PAIRCAP 512
 #endif
-constexpr int BD_NBUF = DM2_BD_NBUF;          // 2: pair records double buffered (2 barriers / batch); 1: single (3 barriers, 12 KB less LDS)
-#ifndef DM2_BD_WAVES
-#define DM2_BD_WAVES 3
+#ifndef DM2_BQ_TAILMIN
+#define DM2_BQ_TAILMIN 0      // a last round with fewer survivors than this is cut off and its faces staged again
 #endif
-constexpr int BD_ACC = 32;
-constexpr int B_DV = 0, B_DC = 9, B_DZ = 18, B_OP = 21, B_IN = 22, B_AA = 23, B_N = 29, B_FLAG = 31;
-constexpr uint32_t BF_BLEND = 1u, BF_ACTIVE = 2u;
+constexpr int BQ_CHUNK = DM2_BQ_CHUNK;
+constexpr int BQ_PAIRCAP = DM2_BQ_PAIRCAP;
+constexpr int BQ_TAILMIN = DM2_BQ_TAILMIN;
+constexpr int BQ_QCAP = ((BQ_PAIRCAP + 3) / 4 + 63) & ~63;     // queue region of one wave
+static_assert(BQ_CHUNK <= 64, "one mask bit per staged face");
+static_assert(BQ_PAIRCAP >= TILE_PIX, "a single face may own 256 pairs");
 
-struct __attribute__((aligned(16))) BwdPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
-static_assert(sizeof(BwdPair) == 32, "BwdPair");
+constexpr int BQ_ACC = 32;
+constexpr int Q_DV = 0, Q_DC = 9, Q_DZ = 18, Q_OP = 21, Q_IN = 22, Q_AA = 23, Q_N = 29, Q_FLAG = 31;
+constexpr uint32_t QB_BLEND = 1u, QB_ACTIVE = 2u;
 
-// DPP row shifts (16-lane rows; lanes shifted in from outside the row read 0)
-template <int N> __device__ __forceinline__ int dpp_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
-template <int N> __device__ __forceinline__ int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
-template <int N> __device__ __forceinline__ float dpp_shr_f(float v) { return __int_as_float(dpp_shr_i<N>(__float_as_int(v))); }
-// inclusive segmented sum inside a row of 16 lanes; sK = "lane l-K belongs to the same run"
-__device__ __forceinline__ void seg_scan16(float& v, bool s1, bool s2, bool s4, bool s8) {
-    float t = dpp_shr_f<1>(v); v += s1 ? t : 0.f;
-    t = dpp_shr_f<2>(v); v += s2 ? t : 0.f;
-    t = dpp_shr_f<4>(v); v += s4 ? t : 0.f;
-    t = dpp_shr_f<8>(v); v += s8 ? t : 0.f;
-}
+struct __attribute__((aligned(16))) BqPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
+static_assert(sizeof(BqPair) == 32, "BqPair");
 
-__global__ void __launch_bounds__(TILE_PIX, DM2_BD_WAVES)
-k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
+__global__ void __launch_bounds__(TILE_PIX, 3)
+k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                         float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
                         float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts STAMP_PARAM) {
-    __shared__ FaceRec recs[BD_CHUNK];
-    __shared__ float acc[BD_CHUNK * BD_ACC];
-    __shared__ BwdPair s_pair[BD_NBUF][TILE_PIX];
+    __shared__ FaceRec recs[BQ_CHUNK];
+    __shared__ float acc[BQ_CHUNK * BQ_ACC];
+    __shared__ BqPair s_pair[TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
-    __shared__ float s_dL[TILE_PIX * 4];
-    __shared__ int s_off[BD_CHUNK + 1];
-    __shared__ int s_jlo[BD_CHUNK + 1];                        // first face of every 256-pair batch of the chunk
-    __shared__ uint32_t s_rect[BD_CHUNK];
+    __shared__ int s_off[BQ_CHUNK + 1];
+    __shared__ uint32_t s_rect[BQ_CHUNK];
     __shared__ int s_wave[4];
+    __shared__ int s_wtot[4];                                  // survivors per wave
     __shared__ int s_inv[17];
-    __shared__ unsigned long long s_mask[BD_NBUF][TILE_PIX];   // per pixel: faces of the current batch that blend into it
-    __shared__ uint32_t s_ovf[BD_NBUF][TILE_PIX];              // per pixel: it also has pairs of faces beyond the 64 mask bits
+    __shared__ uint16_t s_slot[BQ_PAIRCAP];                    // per pair: survivors before it within its wave's range
+    __shared__ uint32_t s_queue[4 * BQ_QCAP];                  // survivors: q | face << 8 | corner mask << 14
+    __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk that blend into it in this round
     __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
     __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
     __shared__ uint32_t s_max_lc;
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     STAMP_DECL
     fill_inv_table(s_inv);
-#pragma unroll
-    for (int u = 0; u < BD_NBUF; u++) { s_mask[u][tid] = 0; s_ovf[u][tid] = 0; }
+    s_mask[tid] = 0;
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -105,7 +101,6 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
         last_contributor = is.n_contrib[pix];
         dLc0 = dL_dcolor[3 * pix]; dLc1 = dL_dcolor[3 * pix + 1]; dLc2 = dL_dcolor[3 * pix + 2];
         dLd = dL_ddepth[pix];
-        s_dL[tid * 4] = dLc0; s_dL[tid * 4 + 1] = dLc1; s_dL[tid * 4 + 2] = dLc2; s_dL[tid * 4 + 3] = dLd;
     }
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
@@ -131,7 +126,8 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     for (int base = 0; base < total; base += n) {
         __syncthreads();                                            // previous chunk flushed, LDS reusable
         STAMP(1)
-        n = min(BD_CHUNK, total - base);
+        // ---- phase A ----------------------------------------------------------------------
+        n = min(BQ_CHUNK, total - base);
         const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
@@ -142,45 +138,97 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             s_rect[tid] = rect;
         }
         STAMP(2)
-        for (int k = tid; k < n * BD_ACC; k += TILE_PIX) acc[k] = 0.f;
+        for (int k = tid; k < n * BQ_ACC; k += TILE_PIX) acc[k] = 0.f;
         int tot;
         const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        int nb = (tot + TILE_PIX - 1) / TILE_PIX;
-        if (tid < n) { s_off[tid] = ex; note_batch_starts(s_jlo, tid, ex, cnt); }
-        if (tid == n) { s_off[n] = tot; s_jlo[nb] = n; }
+        if (tid < n) s_off[tid] = ex;
+        if (tid == n) s_off[n] = tot;
         __syncthreads();
-        cut_to_full_batches(s_off, s_jlo, last_chunk, n, tot, nb);
+        if (tot > BQ_PAIRCAP) {                                     // cut 1: faces [0, n) hold at most PAIRCAP pairs
+            n = find_face(s_off, n, BQ_PAIRCAP);                    // >= 1: a face owns at most 256 pairs
+            tot = s_off[n];
+        }
         STAMP(3)
 
-        for (int bi = 0; bi < nb; bi++) {
-            // ---- phase B ------------------------------------------------------------------
-            const int k = bi * TILE_PIX + tid;
-            const bool have = k < tot;
+        // ---- phase B1: classify, compact survivors in pair order ---------------------------
+        const int Q = (((tot + 3) >> 2) + 63) & ~63;               // pairs per wave, whole rounds of 64
+        int wcount = 0;
+        for (int r = 0; r < Q; r += 64) {
+            const int k = wid * Q + r + lane;
+            bool surv = false;
+            uint32_t entry = 0;
+            if (k < tot) {
+                const int j = find_face(s_off, n, k);
+                int qx, qy;
+                pair_xy(s_rect[j], k - s_off[j], s_inv, qx, qy);
+                uint32_t cmask = 0xF;
+                surv = true;
+                if (use_aa) {
+                    const float pxmin = (float)(uint32_t)(X0a + qx), pymin = (float)(uint32_t)(Y0a + qy);
+                    // (the rectangle already is the exact set of pixels that pass the bbox test, aa.h:96-101)
+                    surv = classify_pixel(recs[j].aa, pxmin, pxmin + 1, pymin, pymin + 1, cmask);
+                }
+                entry = (uint32_t)(qy * TILE + qx) | ((uint32_t)j << 8) | (cmask << 14);
+            }
+            const unsigned long long bal = __ballot(surv);
+            const int before = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (k < tot) s_slot[k] = (uint16_t)before;
+            if (surv) s_queue[wid * BQ_QCAP + before] = entry;
+            wcount += __popcll(bal);
+        }
+        if (lane == 0) s_wtot[wid] = wcount;
+        __syncthreads();
+        STAMP(4)
+        const int wb1 = s_wtot[0], wb2 = wb1 + s_wtot[1], wb3 = wb2 + s_wtot[2];
+        int S = wb3 + s_wtot[3];
+        // global survivor prefix at pair k (k <= tot)
+        auto surv_before = [&](int k) -> int {
+            if (k >= tot) return S;
+            const int w = (k >= Q) + (k >= 2 * Q) + (k >= 3 * Q);
+            return (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3))) + (int)s_slot[k];
+        };
+        if (BQ_TAILMIN > 0 && !last_chunk && S > TILE_PIX && (S & (TILE_PIX - 1)) != 0 && (S & (TILE_PIX - 1)) < BQ_TAILMIN) {
+            // cut 2: drop a nearly empty last round; its faces are staged again by the next chunk
+            const int target = S & ~(TILE_PIX - 1);
+            int lo = 1, hi = n;                                     // surv_before(off[1]) <= 256 <= target < S = surv_before(off[n])
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (surv_before(s_off[mid]) <= target) lo = mid; else hi = mid;
+            }
+            const int S2 = surv_before(s_off[lo]);
+            n = lo; tot = s_off[lo]; S = S2;
+        }
+
+        for (int r0 = 0; r0 < S; r0 += TILE_PIX) {
+            // ---- phase B2 -----------------------------------------------------------------
+            const int s = r0 + tid;
+            const bool have = s < S;
             int j = 0, q = 0;
             float dg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float i0 = 0.f, i1 = 0.f, i2 = 0.f, ratio = 0.f, alpha = 0.f;
             int code = 0;
             bool blend = false;
             if (have) {
-                j = find_face_in(s_off, s_jlo[bi], min(s_jlo[bi + 1] + 1, n), k);
-                const uint32_t rect = s_rect[j];
-                int qx, qy;
-                pair_xy(rect, k - s_off[j], s_inv, qx, qy);
-                q = qy * TILE + qx;
+                const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
+                const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
+                const uint32_t entry = s_queue[w * BQ_QCAP + (s - wb)];
+                q = (int)(entry & 255u); j = (int)((entry >> 8) & 63u);
+                const uint32_t cmask = entry >> 14;
                 const FaceRec& fc = recs[j];
-                const float pxmin = (float)(uint32_t)(X0a + qx), pxmax = pxmin + 1;
-                const float pymin = (float)(uint32_t)(Y0a + qy), pymax = pymin + 1;
+                const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pxmax = pxmin + 1;
+                const float pymin = (float)(uint32_t)(Y0a + (q >> 4)), pymax = pymin + 1;
                 float oarea = 0.f;
                 bool live = true;
                 if (use_aa) {
-#ifdef DM2_BWD_FAN_GRAD     // reference's per-fan-triangle accumulation order (slower; kept for A/B)
+#ifdef DM2_BWD_FAN_GRAD     // reference's per-fan-triangle accumulation order of the Jacobian (slower; kept for A/B)
+                    (void)cmask;
                     const int err = tri_pix_overlap_area_lds<true>(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
 #else
-                    const int err = tri_pix_overlap_area_grad(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
+                    const int err = clip_area_grad_classified(fc.aa, pxmin, pxmax, pymin, pymax, cmask, pix_area, s_polyx + tid, s_polyy + tid, oarea, dg);
 #endif
                     live = !((err != 0) || (oarea == 0.0f));
                 }
-                BwdPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
+                BqPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
                 if (live) {
                     ratio = oarea / pix_area;
                     const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
@@ -200,48 +248,29 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                             out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
                             alpha = fc.opacity * ratio;
                             out.alpha = alpha;
-                            out.flags = BF_BLEND;
+                            out.flags = QB_BLEND;
                             blend = true;
                         }
                     }
                 }
-                s_pair[bi & (BD_NBUF - 1)][tid] = out;
-                if (blend) {
-                    const int bit = j - s_jlo[bi];
-                    if (bit < 64) atomicOr(&s_mask[bi & (BD_NBUF - 1)][q], 1ull << bit);
-                    else s_ovf[bi & (BD_NBUF - 1)][q] = 1;
-                }
+                s_pair[tid] = out;
+                if (blend) atomicOr(&s_mask[q], 1ull << j);
             }
-            STAMP(4)
-            __syncthreads();
             STAMP(5)
+            __syncthreads();
 
             // ---- phase C: per-pixel back-to-front replay ------------------------------------
             {
-                const int k0 = bi * TILE_PIX, k1 = min(k0 + TILE_PIX, tot);
-                unsigned long long m = s_mask[bi & (BD_NBUF - 1)][tid];
-                s_mask[bi & (BD_NBUF - 1)][tid] = 0;
-                const bool ovf = s_ovf[bi & (BD_NBUF - 1)][tid] != 0;
-                s_ovf[bi & (BD_NBUF - 1)][tid] = 0;
-                const int jlo = s_jlo[bi];
-                const int jhi = ovf ? find_face(s_off, n, k1 - 1) : jlo;
-                int jover = jlo + 64;
-                // faces flagged in the mask first (ascending = back to front), then any beyond the 64 mask bits
-                while (m || (ovf && jover <= jhi)) {
-                    // (deriving the slot straight from the mask bit, as the forward does, costs registers here:
-                    // 3.07 ms instead of 2.91 ms at cfg4 -- this kernel sits on its 168-VGPR budget)
-                    int jj;
-                    if (m) { jj = jlo + __ffsll((long long)m) - 1; m &= m - 1; }
-                    else jj = jover++;
-                    const int o = s_off[jj];
-                    if (s_off[jj + 1] == o) continue;
-                    const int kk = pixel_pair(s_rect[jj], o, lx, ly);
-                    if (kk < k0 || kk >= k1) continue;
-                    const int kidx = kk - k0;
+                unsigned long long m = s_mask[tid];
+                s_mask[tid] = 0;
+                while (m) {                                                       // ascending face = back to front
+                    const int jj = __ffsll((long long)m) - 1;
+                    m &= m - 1;
                     const uint32_t e = (uint32_t)(total - 1 - base - jj);        // 0-based position in the list
                     if (e >= last_contributor) continue;                          // backward.cu:219-221
-                    BwdPair& pr = s_pair[bi & (BD_NBUF - 1)][kidx];
-                    if (!(pr.flags & BF_BLEND)) continue;
+                    // a mask bit is only set by a record of this round for this pixel
+                    const int kk = pixel_pair(s_rect[jj], s_off[jj], lx, ly);
+                    BqPair& pr = s_pair[surv_before(kk) - r0];
                     const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
                     if (!T_first_pass) T = T / (1.f - a);                         // backward.cu:340-348
                     T_first_pass = false;
@@ -266,7 +295,9 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         dL_dalpha += (-T_final / (1.f - a)) * bg_dot;
                         dL_dalpha += (-T_final / (1.f - a)) * bd_dot;
                     }
-                    pr.T = T; pr.dL_dalpha = dL_dalpha; pr.flags = BF_BLEND | BF_ACTIVE;
+                    pr.T = T; pr.dL_dalpha = dL_dalpha; pr.flags = QB_BLEND | QB_ACTIVE;
+                    // phase D needs this pixel's loss gradients, not the colours any more: hand them over in place
+                    pr.c0 = dLc0; pr.c1 = dLc1; pr.c2 = dLc2; pr.depth = dLd;
                 }
             }
             STAMP(6)
@@ -274,21 +305,21 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
             STAMP(8)
 
             // ---- phase D: chain rule + per-entry accumulation -------------------------------
-            float gv[B_N];
+            float gv[Q_N];
 #pragma unroll
-            for (int c = 0; c < B_N; c++) gv[c] = 0.f;
+            for (int c = 0; c < Q_N; c++) gv[c] = 0.f;
             bool active = false;
             if (have && blend) {
-                const BwdPair pr = s_pair[bi & (BD_NBUF - 1)][tid];
-                if (pr.flags & BF_ACTIVE) {
+                const BqPair pr = s_pair[tid];
+                if (pr.flags & QB_ACTIVE) {
                     active = true;
                     const FaceRec& fc = recs[j];
                     const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
-                    const float qc0 = s_dL[q * 4], qc1 = s_dL[q * 4 + 1], qc2 = s_dL[q * 4 + 2], qd = s_dL[q * 4 + 3];
+                    const float qc0 = pr.c0, qc1 = pr.c1, qc2 = pr.c2, qd = pr.depth;   // dL/dcolour, dL/ddepth of the pixel (written by phase C)
                     const float intense = fc.intense, opacity = fc.opacity;
                     const float dics[3] = {qc0 * alpha * Tq, qc1 * alpha * Tq, qc2 * alpha * Tq};
                     const float did = qd * alpha * Tq;
-                    gv[B_OP] = dL_dalpha * ratio;
+                    gv[Q_OP] = dL_dalpha * ratio;
                     const float dL_dratio = (dL_dalpha * opacity) * temp;
                     const float dL_doarea = dL_dratio / pix_area;
                     float dL_di0 = 0.f, dL_di1 = 0.f, dL_di2 = 0.f, dL_dfint = 0.f;
@@ -297,14 +328,14 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         dL_di0 += fc.col[ch] * dics[ch] * intense;
                         dL_di1 += fc.col[3 + ch] * dics[ch] * intense;
                         dL_di2 += fc.col[6 + ch] * dics[ch] * intense;
-                        gv[B_DC + ch] = 0.f + i0 * dics[ch] * intense;
-                        gv[B_DC + 3 + ch] = 0.f + i1 * dics[ch] * intense;
-                        gv[B_DC + 6 + ch] = 0.f + i2 * dics[ch] * intense;
+                        gv[Q_DC + ch] = 0.f + i0 * dics[ch] * intense;
+                        gv[Q_DC + 3 + ch] = 0.f + i1 * dics[ch] * intense;
+                        gv[Q_DC + 6 + ch] = 0.f + i2 * dics[ch] * intense;
                         dL_dfint += (i0 * fc.col[ch] + i1 * fc.col[3 + ch] + i2 * fc.col[6 + ch]) * dics[ch];
                     }
-                    gv[B_IN] = dL_dfint;
+                    gv[Q_IN] = dL_dfint;
                     dL_di0 += fc.dep[0] * did; dL_di1 += fc.dep[1] * did; dL_di2 += fc.dep[2] * did;
-                    gv[B_DZ + 0] = 0.f + i0 * did; gv[B_DZ + 1] = 0.f + i1 * did; gv[B_DZ + 2] = 0.f + i2 * did;
+                    gv[Q_DZ + 0] = 0.f + i0 * did; gv[Q_DZ + 1] = 0.f + i1 * did; gv[Q_DZ + 2] = 0.f + i2 * did;
                     float diuc_diu, diuc_div, divc_diu, divc_div;
                     clamp_bary_uv_grad(code, diuc_diu, diuc_div, divc_diu, divc_div);
                     const float di0_diu = -1.f * diuc_diu + -1.f * divc_diu, di0_div = -1.f * diuc_div + -1.f * divc_div;
@@ -320,17 +351,17 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                     const f3 dp0 = dL_diu * du0 + dL_div * dv0;
                     const f3 dp1 = dL_diu * du1 + dL_div * dv1;
                     const f3 dp2 = dL_diu * du2 + dL_div * dv2;
-                    gv[B_DV + 0] = dp0.x; gv[B_DV + 1] = dp0.y; gv[B_DV + 2] = dp0.z;
-                    gv[B_DV + 3] = dp1.x; gv[B_DV + 4] = dp1.y; gv[B_DV + 5] = dp1.z;
-                    gv[B_DV + 6] = dp2.x; gv[B_DV + 7] = dp2.y; gv[B_DV + 8] = dp2.z;
+                    gv[Q_DV + 0] = dp0.x; gv[Q_DV + 1] = dp0.y; gv[Q_DV + 2] = dp0.z;
+                    gv[Q_DV + 3] = dp1.x; gv[Q_DV + 4] = dp1.y; gv[Q_DV + 5] = dp1.z;
+                    gv[Q_DV + 6] = dp2.x; gv[Q_DV + 7] = dp2.y; gv[Q_DV + 8] = dp2.z;
 #pragma unroll
-                    for (int c = 0; c < 6; c++) gv[B_AA + c] = dL_doarea * dg[c];
+                    for (int c = 0; c < 6; c++) gv[Q_AA + c] = dL_doarea * dg[c];
                 }
             }
-            // Pairs are face-major, so the lanes of one face are neighbours.  Sum the 29 partials over the run of
-            // equal faces inside each row of 16 lanes with DPP shifts (pure VALU), then only the last lane of each
-            // run touches LDS: ~8 instead of up to 64 lane-atomics per ds_add_f32 (the LDS atomic unit was the
-            // bottleneck of this phase).
+            // Survivors are face-major, so the lanes of one face are neighbours.  Sum the 29 partials over the run
+            // of equal faces inside each row of 16 lanes with DPP shifts (pure VALU), then only the last lane of
+            // each run touches LDS: ~8 instead of up to 64 lane-atomics per ds_add_f32 (the LDS atomic unit was
+            // the bottleneck of this phase).
             {
                 const int jkey = have ? j : -1;
                 const int l16 = tid & 15;
@@ -345,36 +376,36 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 float nact = active ? 1.f : 0.f;
                 seg_scan16(nact, s1, s2, s4, s8);
 #pragma unroll
-                for (int c = 0; c < B_N; c++) seg_scan16(gv[c], s1, s2, s4, s8);
+                for (int c = 0; c < Q_N; c++) seg_scan16(gv[c], s1, s2, s4, s8);
                 const bool run_end = (l16 == 15) | (kn != jkey);
                 if (run_end && jkey >= 0 && nact > 0.f) {
-                    float* a = acc + j * BD_ACC;
+                    float* a = acc + j * BQ_ACC;
 #pragma unroll
-                    for (int c = 0; c < B_N; c++) atomicAdd(a + c, gv[c]);
-                    a[B_FLAG] = 1.0f;
+                    for (int c = 0; c < Q_N; c++) atomicAdd(a + c, gv[c]);
+                    a[Q_FLAG] = 1.0f;
                 }
             }
             STAMP(9)
-            if (BD_NBUF == 1) __syncthreads();      // single-buffered pair records: D(b) must finish before B(b+1) overwrites them
+            __syncthreads();      // single-buffered records: D(r) must finish before B2(r+1) overwrites them
         }
         __syncthreads();
         STAMP(10)
 
         // ---- flush: lane = (entry, component); 8 entries per pass --------------------------
         const int comp = tid & 31;
-        if (comp < B_N) {
+        if (comp < Q_N) {
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
-                const float* a = acc + e * BD_ACC;
-                if (a[B_FLAG] == 0.f) continue;
+                const float* a = acc + e * BQ_ACC;
+                if (a[Q_FLAG] == 0.f) continue;
                 const FaceRec& fc = recs[e];
                 const float val = a[comp];
                 float* dst;
-                if (comp < B_DC) dst = dL_dverts + 3 * (int64_t)fc.vid[comp / 3] + (comp % 3);
-                else if (comp < B_DZ) dst = dL_dverts_color + 3 * (int64_t)fc.vid[(comp - B_DC) / 3] + ((comp - B_DC) % 3);
-                else if (comp < B_OP) dst = dL_dverts_ndc + ((int64_t)b * d.P + fc.vid[comp - B_DZ]) * 3 + 2;
-                else if (comp == B_OP) dst = dL_dfaces_opacity + fc.face_id;
-                else if (comp == B_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
-                else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - B_AA);
+                if (comp < Q_DC) dst = dL_dverts + 3 * (int64_t)fc.vid[comp / 3] + (comp % 3);
+                else if (comp < Q_DZ) dst = dL_dverts_color + 3 * (int64_t)fc.vid[(comp - Q_DC) / 3] + ((comp - Q_DC) % 3);
+                else if (comp < Q_OP) dst = dL_dverts_ndc + ((int64_t)b * d.P + fc.vid[comp - Q_DZ]) * 3 + 2;
+                else if (comp == Q_OP) dst = dL_dfaces_opacity + fc.face_id;
+                else if (comp == Q_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
+                else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - Q_AA);
                 atomicAdd(dst, val);
             }
         }
@@ -383,13 +414,13 @@ k_render_backward_dense(dm2_render_desc d, const uint2* __restrict__ ranges, con
     STAMP_FLUSH
 }
 
-void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                                   float* dL_daa_face_verts, hipStream_t st) {
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);
-    hipLaunchKernelGGL(k_render_backward_dense, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+    hipLaunchKernelGGL(k_render_backward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
                        dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts STAMP_ARG(1));
 }
 

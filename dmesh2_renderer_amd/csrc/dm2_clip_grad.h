@@ -126,6 +126,12 @@ __device__ __forceinline__ void corner_grad_sel(const AAFace& f, uint32_t code, 
     rows_add(g, rowb, b0, b1);
 }
 
+// aa.h:151-441 with Jacobian for a pixel that passed classify_pixel (dm2_clip_area.h) with corner mask `inside`.
+// Returns non-zero on any reference error; area / g valid when 0.
+__device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                                         uint32_t inside, float pix_area, float* polyx, float* polyy,
+                                                         float& area, float* g);
+
 // aa.h:446-504 with Jacobian.  Returns non-zero on any reference error; area / g valid when 0.
 __device__ __forceinline__ int tri_pix_overlap_area_grad(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
                                                          float pix_area, float* polyx, float* polyy, float& area, float* g) {
@@ -133,19 +139,17 @@ __device__ __forceinline__ int tri_pix_overlap_area_grad(const AAFace& f, float 
 #pragma unroll
     for (int k = 0; k < 6; k++) g[k] = 0.f;
     if ((pxmax < f.bb[0]) || (pxmin > f.bb[1]) || (pymax < f.bb[2]) || (pymin > f.bb[3])) return 0;
-    uint32_t inside = 0xF;
-    bool outside = false;
+    uint32_t inside;
+    if (!classify_pixel(f, pxmin, pxmax, pymin, pymax, inside)) return 0;
+    return clip_area_grad_classified(f, pxmin, pxmax, pymin, pymax, inside, pix_area, polyx, polyy, area, g);
+}
+
+__device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                                         uint32_t inside, float pix_area, float* polyx, float* polyy,
+                                                         float& area, float* g) {
+    area = 0.f;
 #pragma unroll
-    for (int ti = 0; ti < 3; ti++) {
-        const float nx = f.n[2 * ti], ny = f.n[2 * ti + 1], c = f.c[ti];
-        const bool i0 = (pxmin * nx) + (pymin * ny) - c >= 0;
-        const bool i1 = (pxmax * nx) + (pymin * ny) - c >= 0;
-        const bool i2 = (pxmax * nx) + (pymax * ny) - c >= 0;
-        const bool i3 = (pxmin * nx) + (pymax * ny) - c >= 0;
-        outside = outside || !(i0 || i1 || i2 || i3);
-        inside &= (uint32_t)i0 | ((uint32_t)i1 << 1) | ((uint32_t)i2 << 2) | ((uint32_t)i3 << 3);
-    }
-    if (outside) return 0;
+    for (int k = 0; k < 6; k++) g[k] = 0.f;
     if (inside == 0xF) { area = pix_area; return 0; }                 // aa.h:493-496: zero Jacobian
 #ifdef DM2_ABLATE_CLIP
     area = 0.5f * pix_area; return 0;

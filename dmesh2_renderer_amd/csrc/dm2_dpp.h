@@ -1,0 +1,19 @@
+// dm2_dpp.h -- DPP row-shift helpers and the segmented row scan used by the backward kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dm2 {
+
+// DPP row shifts (16-lane rows; lanes shifted in from outside the row read 0)
+template <int N> __device__ __forceinline__ int dpp_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ float dpp_shr_f(float v) { return __int_as_float(dpp_shr_i<N>(__float_as_int(v))); }
+// inclusive segmented sum inside a row of 16 lanes; sK = "lane l-K belongs to the same run"
+__device__ __forceinline__ void seg_scan16(float& v, bool s1, bool s2, bool s4, bool s8) {
+    float t = dpp_shr_f<1>(v); v += s1 ? t : 0.f;
+    t = dpp_shr_f<2>(v); v += s2 ? t : 0.f;
+    t = dpp_shr_f<4>(v); v += s4 ? t : 0.f;
+    t = dpp_shr_f<8>(v); v += s8 ? t : 0.f;
+}
+
+}  // namespace dm2

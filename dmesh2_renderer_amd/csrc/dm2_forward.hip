@@ -107,11 +107,7 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                            float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
-#ifdef DM2_FWD_BATCHED
-        launch_render_forward_dense(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, st);
-#else
         launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, st);
-#endif
         return;
     }
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);

@@ -75,30 +75,6 @@ __device__ __forceinline__ int find_face_in(const int* off, int lo, int hi, int 
 }
 __device__ __forceinline__ int find_face(const int* off, int n, int k) { return find_face_in(off, 0, n, k); }
 
-// First face of every 256-pair batch, written by the face's own staging lane (ex = its exclusive
-// prefix, cnt = its pair count): face j holds pairs [ex, ex+cnt), so it is find_face(b*256) for the
-// batch boundaries inside that interval.  jlo[nb] = n closes the table.
-__device__ __forceinline__ void note_batch_starts(int* jlo, int j, int ex, int cnt) {
-    for (int b = (ex + 255) >> 8; (b << 8) < ex + cnt; b++) jlo[b] = j;
-}
-
-// Partial last batches waste lanes (a chunk of ~30 faces gives 1.4 batches of pairs).  Unless this is
-// the tile's last chunk, keep only the leading faces whose pairs fill whole batches and let the rest be
-// staged again at the head of the next chunk: with m = tot/256 full batches, the face that holds pair
-// m*256 is jlo[m]; faces [0, jlo[m]) hold off[jlo[m]] pairs, in (m*256 - 256, m*256].  Block uniform.
-#ifndef DM2_FILL_CUT
-#define DM2_FILL_CUT 1
-#endif
-__device__ __forceinline__ void cut_to_full_batches(const int* off, const int* jlo, bool last_chunk, int& n, int& tot, int& nb) {
-#if DM2_FILL_CUT
-    if (!last_chunk && tot > TILE_PIX && (tot & (TILE_PIX - 1)) != 0) {
-        nb = tot / TILE_PIX;
-        n = jlo[nb];
-        tot = off[n];
-    }
-#endif
-}
-
 // local pair index -> (dx, dy) inside a rectangle of width w <= 16 (local < 256)
 // inv_w[w] = ceil(65536 / w), w = 1..16 (LDS table filled by fill_inv_table)
 __device__ __forceinline__ void fill_inv_table(int* inv_w) {

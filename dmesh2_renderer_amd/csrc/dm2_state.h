@@ -108,9 +108,7 @@ void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const 
                            float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
-void launch_render_forward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
-void launch_render_backward_dense(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                                   float* dL_daa_face_verts, hipStream_t st);

@@ -112,8 +112,8 @@ CASES = [
     dict(W=96, H=80, F=600, seed=6, temp=1.0, K=20, cams=3, batch_idx=(2, 0),
          patch_min=[[16, 8], [5, 3]], pw=40, ph=33),                      # batch of patches at different offsets
     dict(W=128, H=128, F=3000, seed=7, temp=1.0, K=20, dc=12.0),          # deep: early termination T < 1e-4
-    dict(W=64, H=64, F=20000, seed=8, temp=1.0, K=20, dc=1.5),            # sub-pixel faces: > 64 faces per 256-pair batch
-    dict(W=48, H=48, F=40, seed=9, temp=1.0, K=20, dc=60.0),              # huge faces: every face covers whole tiles
+    dict(W=64, H=64, F=20000, seed=8, temp=1.0, K=20, dc=1.5),            # sub-pixel faces: chunks full of 1-4 pixel rectangles
+    dict(W=48, H=48, F=40, seed=9, temp=1.0, K=20, dc=60.0),              # huge faces: every face covers whole tiles (pair / survivor cuts)
 ]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-segment cycle shares of the dense composite kernels (needs libdm2_hip_stamps.so,
+"""Diagnostic: per-segment cycle shares of the composite kernels (needs libdm2_hip_stamps.so,
 built with `make -C dmesh2_renderer_amd/csrc EXTRA=-DDM2_STAMPS BUILD=build_stamps OUT=libdm2_hip_stamps.so`).
 Never used for reported timings (the stamps perturb the kernels)."""
 import ctypes
@@ -15,9 +15,10 @@ from dmesh2_renderer_amd import _C  # noqa: E402
 _C.LIB_PATH = os.path.join(ROOT, "dmesh2_renderer_amd", "csrc", os.environ.get("DM2_STAMP_LIB", "libdm2_hip_stamps.so"))
 import bench  # noqa: E402
 
-FWD = ["prologue", "top barrier", "stage faces", "scan+barrier", "phase B (pairs)", "barrier after B", "phase C (blend)", "epilogue"]
-BWD = ["prologue", "top barrier", "stage faces", "scan+barrier", "phase B (pairs)", "barrier after B", "phase C (replay)", "-",
-       "barrier after C", "phase D (chain+lds atomics)", "barrier before flush", "flush atomics"]
+FWDQ = ["prologue", "top barrier", "stage faces", "scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
+        "barrier + phase C (blend)", "epilogue"]
+BWDQ = ["prologue", "top barrier", "stage faces", "zero+scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
+        "barrier + phase C (replay)", "-", "barrier after C", "phase D (chain+dpp+lds atomics)", "barriers before flush", "flush atomics"]
 
 
 def main():
@@ -35,7 +36,7 @@ def main():
     torch.cuda.synchronize()
     n = lib.dm2_debug_stamps(buf, 32, 1)
     assert n == 32, n
-    for name, labels, off in (("forward", FWD, 0), ("backward", BWD, 16)):
+    for name, labels, off in (("forward", FWDQ, 0), ("backward", BWDQ, 16)):
         vals = [buf[off + i] for i in range(16)]
         tot = sum(vals)
         print(f"{name}: total wave-cycles {tot:.3e}")

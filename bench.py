@@ -85,6 +85,46 @@ def build_inputs(cfg, device, rank, world):
     return args, dLc, dLd, (W, H, F)
 
 
+def host_prep_ms(cfg, device, iters=10):
+    """Host prep of Renderer.forward (projection + AA tables) forward+backward, reported NEXT TO the metric
+    (excluded from `value`): the reference-shaped torch ops vs the fused HIP prep (8(f) rank 1)."""
+    import dmesh2_renderer_amd as dm2
+    from dmesh2_renderer_amd import prep
+    from dmesh2_renderer_amd.pyrenderer import Triangles
+    W, H, F, ci = CONFIGS[cfg]
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci).to(device)
+    r = dm2.Renderer(sc.mv, sc.proj, W, H, device)
+    mv, proj = r.mv[[0]], r.proj[[0]]
+    verts = sc.verts.clone().requires_grad_(True)
+    faces32 = sc.faces.to(torch.int32)
+    g_ndc = torch.randn((1, verts.shape[0], 3), device=device)
+    g_aa = torch.randn((1, F, 3, 2), device=device)
+
+    def torch_step():
+        verts.grad = None
+        ndc, image = r.compute_verts_ndc_image(verts, mv, proj)
+        corners = image[:, sc.faces.flatten()].view(-1, 3, 2)
+        tri = Triangles(corners[:, 0], corners[:, 1], corners[:, 2])
+        torch.autograd.backward([ndc, tri.verts.reshape(1, F, 3, 2)], [g_ndc, g_aa])
+
+    def fused_step():
+        verts.grad = None
+        out = prep.prepare(verts, faces32, mv, proj, W, H)
+        torch.autograd.backward([out[0], out[2]], [g_ndc, g_aa])
+
+    res = {}
+    for name, fn in (("torch_fwd_bwd", torch_step), ("fused_hip_fwd_bwd", fused_step)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(device)
+        res[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+    return res
+
+
 def cpu_baseline(args, dLc, dLd, W, H, budget_rows=None):
     """Oracle (CPU port) on a band of the frame: same faces, `rows` pixel rows in the middle."""
     from oracle import cpu as orc
@@ -227,6 +267,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not opt.no_cpu:
+            out["config"]["host_prep_ms_not_in_value"] = host_prep_ms(opt.config, device)
             out["cpu_baseline"] = cpu_baseline(args, dLc, dLd, W, H, opt.cpu_rows)
         else:
             out["cpu_baseline"] = None

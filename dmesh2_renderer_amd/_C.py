@@ -48,6 +48,16 @@ class RenderDesc(ctypes.Structure):
     ]
 
 
+class PrepDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", _i32), ("P", _i32), ("F", _i32), ("W", _i32), ("H", _i32),
+        ("verts", _vp), ("faces", _vp), ("mv", _vp), ("proj", _vp),
+        ("verts_ndc", _vp), ("verts_image", _vp), ("aa_face_verts", _vp), ("aa_face_edges", _vp),
+        ("aa_face_edges_iszero", _vp), ("aa_face_edges_recip", _vp), ("aa_face_edges_normal", _vp),
+        ("aa_face_edges_normal_c", _vp),
+    ]
+
+
 class LayersDesc(ctypes.Structure):
     _fields_ = [
         ("B", _i32), ("P", _i32), ("F", _i32), ("T", _i32), ("W", _i32), ("H", _i32), ("L", _i32), ("flags", _i32),
@@ -67,6 +77,8 @@ EXPORTS = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
     "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dm2_prepare_faces": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp]),
+    "dm2_prepare_faces_backward": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
     "dm2_profile_enable": (None, [ctypes.c_int]),
     "dm2_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
@@ -357,6 +369,69 @@ def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, te
             raise _err(lib, "generate_render_layers_cuda (run)")
     generate_render_layers_cuda.last_debug = (R, face_buf, bin_buf, img_buf)      # kept for tests
     return layers, cnt
+
+
+def _prep_desc(verts, faces, mv, proj, width, height, keep):
+    dev = _require_gpu(verts, faces, mv, proj)
+    if verts.dim() != 2 or verts.size(1) != 3:
+        raise RuntimeError("verts must have dimensions (P, 3)")
+    if faces.dim() != 2 or faces.size(1) != 3:
+        raise RuntimeError("faces must have dimensions (F, 3)")
+    if mv.dim() != 3 or tuple(mv.shape[1:]) != (4, 4) or tuple(proj.shape) != tuple(mv.shape):
+        raise RuntimeError("mv and proj must have dimensions (B, 4, 4)")
+    f32, i32 = torch.float32, torch.int32
+    v, fc, m, pr = _c(verts, f32), _c(faces, i32), _c(mv, f32), _c(proj, f32)
+    keep += [v, fc, m, pr]
+    d = PrepDesc()
+    d.B, d.P, d.F, d.W, d.H = m.shape[0], v.shape[0], fc.shape[0], int(width), int(height)
+    d.verts, d.faces, d.mv, d.proj = _ptr(v), _ptr(fc), _ptr(m), _ptr(pr)
+    return d, dev
+
+
+def prepare_faces(verts, faces, mv, proj, width, height, tables=True):
+    """Fused host prep (include/dm2_hip.h: dm2_prepare_faces): -> (verts_ndc (B,P,3), verts_image (B,P,2),
+    aa_face_verts, aa_face_edges, aa_face_edges_iszero (bool), aa_face_edges_recip, aa_face_edges_normal
+    (all (B,F,3,2)), aa_face_edges_normal_c (B,F,3)); with tables=False only the first two."""
+    lib = load_library()
+    keep = []
+    d, dev = _prep_desc(verts, faces, mv, proj, width, height, keep)
+    B, P, F = d.B, d.P, d.F
+    f32 = torch.float32
+    ndc = torch.empty((B, P, 3), dtype=f32, device=dev)
+    image = torch.empty((B, P, 2), dtype=f32, device=dev)
+    d.verts_ndc, d.verts_image = _ptr(ndc), _ptr(image)
+    outs = [ndc, image]
+    if tables:
+        aav, aae, aar, aan = (torch.empty((B, F, 3, 2), dtype=f32, device=dev) for _ in range(4))
+        aaz = torch.empty((B, F, 3, 2), dtype=torch.bool, device=dev)
+        aac = torch.empty((B, F, 3), dtype=f32, device=dev)
+        d.aa_face_verts, d.aa_face_edges, d.aa_face_edges_iszero = _ptr(aav), _ptr(aae), _ptr(aaz)
+        d.aa_face_edges_recip, d.aa_face_edges_normal, d.aa_face_edges_normal_c = _ptr(aar), _ptr(aan), _ptr(aac)
+        outs += [aav, aae, aaz, aar, aan, aac]
+    if lib.dm2_prepare_faces(ctypes.byref(d), _stream(dev)):
+        raise _err(lib, "dm2_prepare_faces")
+    return tuple(outs)
+
+
+def prepare_faces_backward(verts, faces, mv, proj, width, height, g_verts_ndc=None, g_verts_image=None, g_aa_face_verts=None):
+    """d(verts) (P,3) through the fused host prep (dm2_prepare_faces_backward)."""
+    lib = load_library()
+    keep = []
+    d, dev = _prep_desc(verts, faces, mv, proj, width, height, keep)
+    f32 = torch.float32
+    gs = []
+    for g, shape in ((g_verts_ndc, (d.B, d.P, 3)), (g_verts_image, (d.B, d.P, 2)), (g_aa_face_verts, (d.B, d.F, 3, 2))):
+        if g is not None:
+            if tuple(g.shape) != shape:
+                raise RuntimeError(f"upstream gradient has shape {tuple(g.shape)}, expected {shape}")
+            g = _c(g, f32)
+            _require_gpu(verts, g)
+        gs.append(g)
+    scratch = torch.empty((d.B * d.P * 2,), dtype=f32, device=dev) if gs[2] is not None else None
+    out = torch.empty((d.P, 3), dtype=f32, device=dev)
+    if lib.dm2_prepare_faces_backward(ctypes.byref(d), _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(scratch), _ptr(out), _stream(dev)):
+        raise _err(lib, "dm2_prepare_faces_backward")
+    return out
 
 
 def debug_fetch(what, count, aux, num_rendered, scratch, dtype, n):

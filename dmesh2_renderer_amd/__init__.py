@@ -14,6 +14,7 @@ raise ``RuntimeError``.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import torch
@@ -23,6 +24,7 @@ from .pyrenderer import Triangles
 
 __all__ = ["RenderFunction", "Renderer", "LayeredRenderer", "Triangles"]
 
+_FUSED_PREP_DEFAULT = os.environ.get("DM2_FUSED_PREP", "0") == "1"
 _W_EPS = 1e-4   # |w| clamp of the projection, sign kept (reference __init__.py:254-255)
 
 
@@ -94,10 +96,13 @@ class Renderer(torch.nn.Module):
     precomputed for every camera at construction.
     """
 
-    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20):
+    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20, fused_prep=None):
         super().__init__()
         self._setup(mv, proj, width, height, device)
         self.aa_grad_buffer_size = aa_grad_buffer_size
+        # opt-in (not part of the reference's signature): projection + AA tables by the fused HIP prep
+        # (dmesh2_renderer_amd/prep.py) instead of the reference-shaped torch ops below
+        self.fused_prep = _FUSED_PREP_DEFAULT if fused_prep is None else bool(fused_prep)
 
     def _setup(self, mv, proj, width, height, device):
         self.mv = mv
@@ -175,13 +180,22 @@ class Renderer(torch.nn.Module):
         F = faces.shape[0]
         mv = self.mv[batch_mvp_idx]
         proj = self.proj[batch_mvp_idx]
+        ray_o, ray_d = self.select_rays(batch_mvp_idx, batch_patch_min, patch_width, patch_height)
+        f32 = torch.float32
+        if getattr(self, "fused_prep", False):
+            from . import prep
+            (verts_ndc, verts_image, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c) = prep.prepare(
+                verts.to(f32), faces.to(torch.int32), mv.to(f32), proj.to(f32), self.width, self.height)
+            color, depth = RenderFunction.apply(
+                background.to(f32), batch_patch_min.to(torch.int32), patch_width, patch_height,
+                verts.to(f32), faces.to(torch.int32), verts_color.to(f32), faces_opacity.to(f32),
+                verts_ndc, verts_image, faces_intense.to(f32), aa_temperature,
+                aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, self.aa_grad_buffer_size, ray_o.to(f32), ray_d.to(f32))
+            return color, 1.0 - (depth + 1.0) / 2.0
         verts_ndc, verts_image = self.compute_verts_ndc_image(verts, mv, proj)
 
         corners = verts_image[:, faces.flatten()].view(-1, 3, 2)             # (B*F,3,2)
         tri = Triangles(corners[:, 0], corners[:, 1], corners[:, 2])
-        ray_o, ray_d = self.select_rays(batch_mvp_idx, batch_patch_min, patch_width, patch_height)
-
-        f32 = torch.float32
         color, depth = RenderFunction.apply(
             background.to(f32),
             batch_patch_min.to(torch.int32), patch_width, patch_height,
@@ -210,9 +224,10 @@ class LayeredRenderer(Renderer):
     which changes nothing observable.)
     """
 
-    def __init__(self, mv, proj, width, height, device):
+    def __init__(self, mv, proj, width, height, device, fused_prep=None):
         torch.nn.Module.__init__(self)
         self._setup(mv, proj, width, height, device)
+        self.fused_prep = _FUSED_PREP_DEFAULT if fused_prep is None else bool(fused_prep)
 
     def generate(self, batch_mvp_idx: Sequence[int], verts: torch.Tensor, faces: torch.Tensor,
                  tets: torch.Tensor, face_tets: torch.Tensor, tet_faces: torch.Tensor,
@@ -220,9 +235,14 @@ class LayeredRenderer(Renderer):
         """-> render_layers (B,H,W,L) int32 face ids (-1 = empty), render_layers_cnt (B,H,W) int32."""
         mv = self.mv[batch_mvp_idx]
         proj = self.proj[batch_mvp_idx]
-        verts_ndc, verts_image = self.compute_verts_ndc_image(verts, mv, proj)
-        ray_o, ray_d = self.ray_o[batch_mvp_idx], self.ray_d[batch_mvp_idx]
         i32, f32 = torch.int32, torch.float32
+        if getattr(self, "fused_prep", False):
+            from . import prep
+            with torch.no_grad():
+                verts_ndc, verts_image = prep.project(verts.to(f32), faces.to(i32), mv.to(f32), proj.to(f32), self.width, self.height)
+        else:
+            verts_ndc, verts_image = self.compute_verts_ndc_image(verts, mv, proj)
+        ray_o, ray_d = self.ray_o[batch_mvp_idx], self.ray_d[batch_mvp_idx]
         return _C.generate_render_layers_cuda(
             self.width, self.height,
             verts.to(f32), faces.to(i32), tets.to(i32), face_tets.to(i32), tet_faces.to(i32),

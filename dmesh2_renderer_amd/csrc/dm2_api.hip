@@ -250,6 +250,35 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, void* face_sc
     return 0;
 }
 
+static int check_prep_desc(const dm2_prep_desc* d) {
+    if (!d) return fail("null descriptor");
+    if (d->B < 0 || d->P < 0 || d->F < 0 || d->W < 0 || d->H < 0) return fail("negative size in descriptor");
+    if (d->B > 65535) return fail("more than 65535 views per call");
+    if (d->P > 0 && d->B > 0 && (!d->verts || !d->mv || !d->proj)) return fail("verts, mv and proj must not be null");
+    if (d->F > 0 && !d->faces) return fail("faces must not be null");
+    return 0;
+}
+
+int dm2_prepare_faces(const dm2_prep_desc* d, void* stream) {
+    if (check_prep_desc(d)) return 1;
+    const bool tables = d->aa_face_verts || d->aa_face_edges || d->aa_face_edges_iszero || d->aa_face_edges_recip ||
+                        d->aa_face_edges_normal || d->aa_face_edges_normal_c;
+    if (tables && d->F > 0 && d->B > 0 && !d->verts_image) return fail("the AA tables are built from verts_image: it must not be null");
+    dm2::launch_prepare_faces(*d, (hipStream_t)stream);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc, const float* g_verts_image,
+                               const float* g_aa_face_verts, float* image_grad_scratch, float* g_verts, void* stream) {
+    if (check_prep_desc(d)) return 1;
+    if (d->P > 0 && !g_verts) return fail("g_verts must not be null");
+    if (g_aa_face_verts && d->F > 0 && d->B > 0 && d->P > 0 && !image_grad_scratch) return fail("image_grad_scratch must not be null");
+    dm2::launch_prepare_faces_backward(*d, g_verts_ndc, g_verts_image, g_aa_face_verts, image_grad_scratch, g_verts, (hipStream_t)stream);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
 int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, const void* scratch, size_t scratch_bytes,
                     void* dst, void* stream) {
     hipStream_t st = (hipStream_t)stream;

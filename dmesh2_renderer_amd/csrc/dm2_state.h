@@ -106,6 +106,9 @@ void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_dep
 
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                            float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
+void launch_prepare_faces(const dm2_prep_desc& d, hipStream_t st);
+void launch_prepare_faces_backward(const dm2_prep_desc& d, const float* g_ndc, const float* g_image, const float* g_aa,
+                                   float* image_grad_scratch, float* g_verts, hipStream_t st);
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
 void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,

@@ -142,6 +142,39 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered,
                    void* image_scratch, size_t image_bytes,
                    int32_t* render_layers, int32_t* render_layers_cnt, void* stream);
 
+/* Host prep of Renderer.forward / LayeredRenderer.generate, fused.
+ * Replaces the ~20 torch kernels of the reference's Python host layer:
+ *   compute_verts_ndc_image  dmesh2_renderer/__init__.py:239-262  (projection, |w| clamp, NDC -> image)
+ *   Triangles                dmesh2_renderer/pyrenderer.py:6-30   (CCW reorder + the six AA tables)
+ * mv / proj are the (B,4,4) matrices of the selected cameras, row-major, applied as
+ * `hom @ mv^T @ proj^T`.  Any of the eight outputs may be NULL (LayeredRenderer needs the
+ * first two only); with F == 0 or all aa_* NULL only the projection runs. */
+typedef struct dm2_prep_desc {
+    int32_t B, P, F;
+    int32_t W, H;                 /* FULL image width / height (Renderer.width/height), not the patch */
+    const float* verts;           /* (P,3) */
+    const int32_t* faces;         /* (F,3) */
+    const float* mv;              /* (B,4,4) */
+    const float* proj;            /* (B,4,4) */
+    float* verts_ndc;             /* (B,P,3) out */
+    float* verts_image;           /* (B,P,2) out (input of the backward when non-NULL there) */
+    float* aa_face_verts;         /* (B,F,3,2) out */
+    float* aa_face_edges;         /* (B,F,3,2) out */
+    uint8_t* aa_face_edges_iszero;/* (B,F,3,2) out, bool */
+    float* aa_face_edges_recip;   /* (B,F,3,2) out */
+    float* aa_face_edges_normal;  /* (B,F,3,2) out */
+    float* aa_face_edges_normal_c;/* (B,F,3) out */
+} dm2_prep_desc;
+
+int dm2_prepare_faces(const dm2_prep_desc* d, void* stream);
+/* The gradient torch autograd sends back through the host prep: upstream gradients of verts_ndc
+ * (B,P,3), verts_image (B,P,2) and aa_face_verts (B,F,3,2) (each may be NULL) -> g_verts (P,3),
+ * overwritten.  image_grad_scratch: B*P*2 floats of caller scratch.  Only the input fields of `d`
+ * are read. */
+int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc, const float* g_verts_image,
+                               const float* g_aa_face_verts, float* image_grad_scratch, float* g_verts,
+                               void* stream);
+
 /* Introspection for tests/bench: copy pieces of the scratch state to caller
  * (device) buffers.  what: 0 ranges (B*tiles*2 u32, from image scratch),
  * 1 face_list (num_rendered u32, from binning scratch), 2 final_T, 3 final_prev_T

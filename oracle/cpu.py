@@ -24,7 +24,7 @@ _c = ctypes
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "build", "libdm2_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("dm2_oracle.cpp", "dm2_oracle_math.hpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("dm2_oracle.cpp", "dm2_oracle_prep.cpp", "dm2_oracle_math.hpp", "Makefile")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -81,6 +81,40 @@ def aa_tables(tri_verts, dtype=np.float32, reorder=True):
     normal_c = (normal * starts).sum(axis=-1).astype(dtype)
     return dict(verts=verts.astype(dtype), edges=edges.astype(dtype), iszero=iszero,
                 recip=recip, normal=normal.astype(dtype), normal_c=normal_c)
+
+
+def prepare_faces(verts, faces, mv, proj, width, height, dtype=np.float32):
+    """Host prep of Renderer.forward (reference __init__.py:239-262, pyrenderer.py:6-30) for the cameras
+    mv/proj (B,4,4): -> dict(verts_ndc (B,P,3), verts_image (B,P,2), verts/edges/recip/normal (B,F,3,2),
+    iszero (B,F,3,2) bool, normal_c (B,F,3))."""
+    suf = "f32" if dtype == np.float32 else "f64"
+    v = _np(verts, dtype); fc = _np(faces, np.int32); m = _np(mv, dtype); pr = _np(proj, dtype)
+    B, P, F = m.shape[0], v.shape[0], fc.shape[0]
+    out = dict(verts_ndc=np.zeros((B, P, 3), dtype), verts_image=np.zeros((B, P, 2), dtype),
+               verts=np.zeros((B, F, 3, 2), dtype), edges=np.zeros((B, F, 3, 2), dtype),
+               iszero=np.zeros((B, F, 3, 2), np.uint8), recip=np.zeros((B, F, 3, 2), dtype),
+               normal=np.zeros((B, F, 3, 2), dtype), normal_c=np.zeros((B, F, 3), dtype))
+    with np.errstate(divide="ignore"):
+        getattr(lib(), "orc_prepare_" + suf)(B, P, F, int(width), int(height), _p(v), _p(fc), _p(m), _p(pr),
+                                             _p(out["verts_ndc"]), _p(out["verts_image"]), _p(out["verts"]), _p(out["edges"]),
+                                             _p(out["iszero"]), _p(out["recip"]), _p(out["normal"]), _p(out["normal_c"]))
+    out["iszero"] = out["iszero"].astype(bool)
+    return out
+
+
+def prepare_faces_backward(verts, faces, mv, proj, width, height, g_ndc=None, g_image=None, g_aa=None, dtype=np.float32):
+    """d(verts) (P,3) that torch autograd sends back through the host prep for upstream gradients of
+    verts_ndc (B,P,3), verts_image (B,P,2) and aa_face_verts (B,F,3,2)."""
+    suf = "f32" if dtype == np.float32 else "f64"
+    v = _np(verts, dtype); fc = _np(faces, np.int32); m = _np(mv, dtype); pr = _np(proj, dtype)
+    B, P, F = m.shape[0], v.shape[0], fc.shape[0]
+    gn = None if g_ndc is None else _np(g_ndc, dtype)
+    gi = None if g_image is None else _np(g_image, dtype)
+    ga = None if g_aa is None else _np(g_aa, dtype)
+    out = np.zeros((P, 3), dtype)
+    getattr(lib(), "orc_prepare_backward_" + suf)(B, P, F, int(width), int(height), _p(v), _p(fc), _p(m), _p(pr),
+                                                  _p(gn), _p(gi), _p(ga), _p(out))
+    return out
 
 
 def aa_overlap(tables, idx, pixmin, dtype=np.float32):

@@ -57,7 +57,6 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ int s_off[FQ_CHUNK + 1];
     __shared__ uint32_t s_rect[FQ_CHUNK];
     __shared__ int s_kb[FQ_CHUNK];                       // pair index of the face's (virtual) tile pixel (0,0): off - y0*w - x0
-    __shared__ int s_wave[4];
     __shared__ int s_wtot[4];                            // survivors per wave
     __shared__ int s_inv[17];
     __shared__ uint16_t s_slot[FQ_PAIRCAP];              // per pair: survivors before it within its wave's range
@@ -115,16 +114,19 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             s_rect[tid] = rect;
         }
         STAMP(2)
-        int tot;
-        const int ex = block_exclusive_scan(cnt, s_wave, tot);
-        if (tid < n) {
-            s_off[tid] = ex;
-            const uint32_t r = s_rect[tid];
-            s_kb[tid] = ex - (int)((r >> 4) & 15u) * ((int)((r >> 8) & 15u) + 1) - (int)(r & 15u);
+        if (wid == 0) {                                             // a chunk is at most 64 faces: all staging lanes are in wave 0
+            const int inc = wave_inclusive_scan(cnt);
+            if (tid < n) {
+                const int ex = inc - cnt;
+                s_off[tid] = ex;
+                const uint32_t r = s_rect[tid];
+                s_kb[tid] = ex - (int)((r >> 4) & 15u) * ((int)((r >> 8) & 15u) + 1) - (int)(r & 15u);
+            }
+            if (lane == 63) s_off[n] = inc;                         // lanes >= n count 0: lane 63 holds the total
         }
-        if (tid == n) s_off[n] = tot;
         __syncthreads();
-        if (tot > FQ_PAIRCAP) {                                     // cut 1: faces [0, n) hold at most PAIRCAP pairs
+        int tot = s_off[n];
+        if (tot > FQ_PAIRCAP) {                                    // cut 1: faces [0, n) hold at most PAIRCAP pairs
             n = find_face(s_off, n, FQ_PAIRCAP);                    // >= 1: a face owns at most 256 pairs
             tot = s_off[n];
         }

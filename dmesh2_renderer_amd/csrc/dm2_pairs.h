@@ -47,6 +47,18 @@ __device__ __forceinline__ int face_pixel_rect(const float bb[4], bool use_bbox,
     return (x1 - x0 + 1) * (y1 - y0 + 1);
 }
 
+// Inclusive scan of one int per lane inside a wave.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    return inc;
+}
+
 // Block-wide exclusive scan of one int per thread (256 threads = 4 waves).
 // s_wave: 4 ints of LDS.  Returns the exclusive prefix; total in `total`.
 __device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave, int& total) {

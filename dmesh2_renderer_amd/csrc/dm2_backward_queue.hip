@@ -307,84 +307,109 @@ k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, con
             STAMP(8)
 
             // ---- phase D: chain rule + per-entry accumulation -------------------------------
-            float gv[Q_N];
+            // Survivors are face-major, so the lanes of one face are neighbours.  Every partial is summed over
+            // the run of equal faces inside its row of 16 lanes with DPP shifts (pure VALU), then only the last
+            // lane of each run touches LDS: ~8 instead of up to 64 lane-atomics per ds_add_f32 (the LDS atomic
+            // unit was the bottleneck of this phase).  The 29 partials are produced and retired in three groups
+            // (colour/depth/opacity, AA corners, world-space corners) to keep the live register set small: all 29
+            // at once needed 168 VGPRs + 4 spilled and ran 2.82 ms at cfg4, grouped 155 VGPRs, no spill, 2.64 ms.
+            const int jkey = have ? j : -1;
+            const int l16 = tid & 15;
+            // NB: every DPP read must execute with all lanes enabled (a lane disabled by a short-circuit
+            // `&&` reads as 0 for its neighbours), hence the unconditional reads first and `&`, `|` below.
+            const int k1 = dpp_shr_i<1>(jkey), k2 = dpp_shr_i<2>(jkey), k4 = dpp_shr_i<4>(jkey), k8 = dpp_shr_i<8>(jkey);
+            const int kn = dpp_shl_i<1>(jkey);
+            const bool s1 = (l16 >= 1) & (k1 == jkey);
+            const bool s2 = (l16 >= 2) & (k2 == jkey);
+            const bool s4 = (l16 >= 4) & (k4 == jkey);
+            const bool s8 = (l16 >= 8) & (k8 == jkey);
+            BqPair pr; pr.flags = 0; pr.T = 0.f; pr.dL_dalpha = 0.f; pr.c0 = pr.c1 = pr.c2 = pr.depth = 0.f;
+            if (have && blend) pr = s_pair[tid];
+            const bool active = (pr.flags & QB_ACTIVE) != 0;
+            float nact = active ? 1.f : 0.f;
+            seg_scan16(nact, s1, s2, s4, s8);
+            const bool emit = ((l16 == 15) | (kn != jkey)) & (jkey >= 0) & (nact > 0.f);
+            float* const arow = acc + j * BQ_ACC;
+            const FaceRec& fcD = recs[j];
+            float dL_diu = 0.f, dL_div = 0.f, dL_doarea = 0.f;
+            {   // group 1: vertex colours, NDC depth, intensity, opacity
+                float g1[14];
 #pragma unroll
-            for (int c = 0; c < Q_N; c++) gv[c] = 0.f;
-            bool active = false;
-            if (have && blend) {
-                const BqPair pr = s_pair[tid];
-                if (pr.flags & QB_ACTIVE) {
-                    active = true;
-                    const FaceRec& fc = recs[j];
+                for (int c = 0; c < 14; c++) g1[c] = 0.f;
+                if (active) {
                     const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
                     const float qc0 = pr.c0, qc1 = pr.c1, qc2 = pr.c2, qd = pr.depth;   // dL/dcolour, dL/ddepth of the pixel (written by phase C)
-                    const float intense = fc.intense, opacity = fc.opacity;
+                    const float intense = fcD.intense, opacity = fcD.opacity;
                     const float dics[3] = {qc0 * alpha * Tq, qc1 * alpha * Tq, qc2 * alpha * Tq};
                     const float did = qd * alpha * Tq;
-                    gv[Q_OP] = dL_dalpha * ratio;
+                    g1[12] = dL_dalpha * ratio;
                     const float dL_dratio = (dL_dalpha * opacity) * temp;
-                    const float dL_doarea = dL_dratio / pix_area;
+                    dL_doarea = dL_dratio / pix_area;
                     float dL_di0 = 0.f, dL_di1 = 0.f, dL_di2 = 0.f, dL_dfint = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        dL_di0 += fc.col[ch] * dics[ch] * intense;
-                        dL_di1 += fc.col[3 + ch] * dics[ch] * intense;
-                        dL_di2 += fc.col[6 + ch] * dics[ch] * intense;
-                        gv[Q_DC + ch] = 0.f + i0 * dics[ch] * intense;
-                        gv[Q_DC + 3 + ch] = 0.f + i1 * dics[ch] * intense;
-                        gv[Q_DC + 6 + ch] = 0.f + i2 * dics[ch] * intense;
-                        dL_dfint += (i0 * fc.col[ch] + i1 * fc.col[3 + ch] + i2 * fc.col[6 + ch]) * dics[ch];
+                        dL_di0 += fcD.col[ch] * dics[ch] * intense;
+                        dL_di1 += fcD.col[3 + ch] * dics[ch] * intense;
+                        dL_di2 += fcD.col[6 + ch] * dics[ch] * intense;
+                        g1[ch] = 0.f + i0 * dics[ch] * intense;
+                        g1[3 + ch] = 0.f + i1 * dics[ch] * intense;
+                        g1[6 + ch] = 0.f + i2 * dics[ch] * intense;
+                        dL_dfint += (i0 * fcD.col[ch] + i1 * fcD.col[3 + ch] + i2 * fcD.col[6 + ch]) * dics[ch];
                     }
-                    gv[Q_IN] = dL_dfint;
-                    dL_di0 += fc.dep[0] * did; dL_di1 += fc.dep[1] * did; dL_di2 += fc.dep[2] * did;
-                    gv[Q_DZ + 0] = 0.f + i0 * did; gv[Q_DZ + 1] = 0.f + i1 * did; gv[Q_DZ + 2] = 0.f + i2 * did;
+                    g1[13] = dL_dfint;
+                    dL_di0 += fcD.dep[0] * did; dL_di1 += fcD.dep[1] * did; dL_di2 += fcD.dep[2] * did;
+                    g1[9] = 0.f + i0 * did; g1[10] = 0.f + i1 * did; g1[11] = 0.f + i2 * did;
                     float diuc_diu, diuc_div, divc_diu, divc_div;
                     clamp_bary_uv_grad(code, diuc_diu, diuc_div, divc_diu, divc_div);
                     const float di0_diu = -1.f * diuc_diu + -1.f * divc_diu, di0_div = -1.f * diuc_div + -1.f * divc_div;
                     const float di1_diu = 1.f * diuc_diu + 0.f * divc_diu, di1_div = 1.f * diuc_div + 0.f * divc_div;
                     const float di2_diu = 0.f * diuc_diu + 1.f * divc_diu, di2_div = 0.f * diuc_div + 1.f * divc_div;
-                    const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
-                    const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+                    dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
+                    dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+                }
+#pragma unroll
+                for (int c = 0; c < 14; c++) seg_scan16(g1[c], s1, s2, s4, s8);
+                if (emit) {
+#pragma unroll
+                    for (int c = 0; c < 12; c++) atomicAdd(arow + Q_DC + c, g1[c]);      // Q_DC..Q_DC+8, Q_DZ..Q_DZ+2 are contiguous
+                    atomicAdd(arow + Q_OP, g1[12]);
+                    atomicAdd(arow + Q_IN, g1[13]);
+                    arow[Q_FLAG] = 1.0f;
+                }
+            }
+            {   // group 2: AA corners
+                float g2[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) g2[c] = dL_doarea * dg[c];                   // dL_doarea is 0 on inactive lanes
+#pragma unroll
+                for (int c = 0; c < 6; c++) seg_scan16(g2[c], s1, s2, s4, s8);
+                if (emit) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) atomicAdd(arow + Q_AA + c, g2[c]);
+                }
+            }
+            {   // group 3: world-space corners through the ray/triangle intersection
+                float g3[9];
+#pragma unroll
+                for (int c = 0; c < 9; c++) g3[c] = 0.f;
+                if (active) {
                     const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
                     const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
-                    const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                    const f3 p0 = {fcD.v[0], fcD.v[1], fcD.v[2]}, p1 = {fcD.v[3], fcD.v[4], fcD.v[5]}, p2 = {fcD.v[6], fcD.v[7], fcD.v[8]};
                     f3 du0, du1, du2, dv0, dv1, dv2;
                     ray_tri_intersection_grad(ro, rd, p0, p1, p2, corrected, du0, du1, du2, dv0, dv1, dv2);
                     const f3 dp0 = dL_diu * du0 + dL_div * dv0;
                     const f3 dp1 = dL_diu * du1 + dL_div * dv1;
                     const f3 dp2 = dL_diu * du2 + dL_div * dv2;
-                    gv[Q_DV + 0] = dp0.x; gv[Q_DV + 1] = dp0.y; gv[Q_DV + 2] = dp0.z;
-                    gv[Q_DV + 3] = dp1.x; gv[Q_DV + 4] = dp1.y; gv[Q_DV + 5] = dp1.z;
-                    gv[Q_DV + 6] = dp2.x; gv[Q_DV + 7] = dp2.y; gv[Q_DV + 8] = dp2.z;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) gv[Q_AA + c] = dL_doarea * dg[c];
+                    g3[0] = dp0.x; g3[1] = dp0.y; g3[2] = dp0.z;
+                    g3[3] = dp1.x; g3[4] = dp1.y; g3[5] = dp1.z;
+                    g3[6] = dp2.x; g3[7] = dp2.y; g3[8] = dp2.z;
                 }
-            }
-            // Survivors are face-major, so the lanes of one face are neighbours.  Sum the 29 partials over the run
-            // of equal faces inside each row of 16 lanes with DPP shifts (pure VALU), then only the last lane of
-            // each run touches LDS: ~8 instead of up to 64 lane-atomics per ds_add_f32 (the LDS atomic unit was
-            // the bottleneck of this phase).
-            {
-                const int jkey = have ? j : -1;
-                const int l16 = tid & 15;
-                // NB: every DPP read must execute with all lanes enabled (a lane disabled by a short-circuit
-                // `&&` reads as 0 for its neighbours), hence the unconditional reads first and `&`, `|` below.
-                const int k1 = dpp_shr_i<1>(jkey), k2 = dpp_shr_i<2>(jkey), k4 = dpp_shr_i<4>(jkey), k8 = dpp_shr_i<8>(jkey);
-                const int kn = dpp_shl_i<1>(jkey);
-                const bool s1 = (l16 >= 1) & (k1 == jkey);
-                const bool s2 = (l16 >= 2) & (k2 == jkey);
-                const bool s4 = (l16 >= 4) & (k4 == jkey);
-                const bool s8 = (l16 >= 8) & (k8 == jkey);
-                float nact = active ? 1.f : 0.f;
-                seg_scan16(nact, s1, s2, s4, s8);
 #pragma unroll
-                for (int c = 0; c < Q_N; c++) seg_scan16(gv[c], s1, s2, s4, s8);
-                const bool run_end = (l16 == 15) | (kn != jkey);
-                if (run_end && jkey >= 0 && nact > 0.f) {
-                    float* a = acc + j * BQ_ACC;
+                for (int c = 0; c < 9; c++) seg_scan16(g3[c], s1, s2, s4, s8);
+                if (emit) {
 #pragma unroll
-                    for (int c = 0; c < Q_N; c++) atomicAdd(a + c, gv[c]);
-                    a[Q_FLAG] = 1.0f;
+                    for (int c = 0; c < 9; c++) atomicAdd(arow + Q_DV + c, g3[c]);
                 }
             }
             STAMP(9)

@@ -28,13 +28,16 @@
 namespace dm2 {
 
 #ifndef DM2_BQ_CHUNK
-#define DM2_BQ_CHUNK 28
+#define DM2_BQ_CHUNK 30      // 3 blocks/CU need <= 54.6 KB LDS (30 faces: 52.3 KB).  A/B at cfg4 on MI355X with TAILMIN 96:
+                             // 28: 2.47 ms, 30: 2.40, 32: 2.40, 33: 2.42, 35 (2 blocks/CU): 3.45
 #endif
 #ifndef DM2_BQ_PAIRCAP
 #define DM2_BQ_PAIRCAP 512
 #endif
 #ifndef DM2_BQ_TAILMIN
-#define DM2_BQ_TAILMIN 0      // a last round with fewer survivors than this is cut off and its faces staged again
+#define DM2_BQ_TAILMIN 256    // a last round with fewer survivors than this is cut off and its faces staged again.  With 256
+                              // a chunk never runs a partial second round (7 barriers for a few dozen lanes of work): cfg4
+                              // backward 2.64 ms (no cut), 2.53 (64), 2.40 (96..192), 2.38 (256, chunk 30)
 #endif
 constexpr int BQ_CHUNK = DM2_BQ_CHUNK;
 constexpr int BQ_PAIRCAP = DM2_BQ_PAIRCAP;

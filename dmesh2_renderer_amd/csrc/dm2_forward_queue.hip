@@ -37,6 +37,10 @@ namespace dm2 {
 constexpr int FQ_CHUNK = DM2_FQ_CHUNK;
 constexpr int FQ_PAIRCAP = DM2_FQ_PAIRCAP;
 constexpr int FQ_SURVCAP = DM2_FQ_SURVCAP;
+#ifndef DM2_FQ_TAILMIN
+#define DM2_FQ_TAILMIN 0      // a last round with fewer survivors than this is cut off and its faces staged again
+#endif
+constexpr int FQ_TAILMIN = DM2_FQ_TAILMIN;
 constexpr int FQ_QCAP = ((FQ_PAIRCAP + 3) / 4 + 63) & ~63;     // queue region of one wave
 static_assert(FQ_CHUNK <= 64, "one mask bit per staged face");
 static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
@@ -106,6 +110,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(1)
         // ---- phase A ----------------------------------------------------------------------
         n = min(FQ_CHUNK, total - base);
+        const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
             stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
@@ -169,11 +174,16 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const int w = (k >= Q) + (k >= 2 * Q) + (k >= 3 * Q);
             return (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3))) + (int)s_slot[k];
         };
-        if (S > FQ_SURVCAP) {                                       // cut 2: largest face prefix with <= SURVCAP survivors
-            int lo = 1, hi = n;                                     // surv_before(off[1]) <= 256 holds, surv_before(off[n]) = S does not
+        // cut 2: at most SURVCAP records fit; and a nearly empty last round of 256 lanes is not worth running --
+        // its faces go to the next chunk (unless this is the tile's last one)
+        int target = S;
+        if (S > FQ_SURVCAP) target = FQ_SURVCAP;
+        else if (FQ_TAILMIN > 0 && !last_chunk && S > TILE_PIX && (S & (TILE_PIX - 1)) != 0 && (S & (TILE_PIX - 1)) < FQ_TAILMIN) target = S & ~(TILE_PIX - 1);
+        if (target < S) {                                           // largest face prefix with <= target survivors
+            int lo = 1, hi = n;                                     // surv_before(off[1]) <= 256 <= target holds, surv_before(off[n]) = S does not
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (surv_before(s_off[mid]) <= FQ_SURVCAP) lo = mid; else hi = mid;
+                if (surv_before(s_off[mid]) <= target) lo = mid; else hi = mid;
             }
             const int S2 = surv_before(s_off[lo]);
             n = lo; tot = s_off[lo]; S = S2;

@@ -3,7 +3,7 @@
 // The reference stages 96-108 B per entry in shared memory and re-reads the AA
 // tables from global memory for every (pixel,face) (forward.cu:228-243,314-317,
 // aa.h:111-120,184-203).  Here everything a (pixel,face) evaluation needs is
-// gathered ONCE per (tile,entry) into a 272-byte LDS record; the per-pixel loop
+// gathered ONCE per (tile,entry) into a 240-byte LDS record; the per-pixel loop
 // then reads it with wave-uniform (broadcast) ds_reads only.
 #pragma once
 #include "dm2_device_math.h"
@@ -11,6 +11,9 @@
 
 namespace dm2 {
 
+#ifndef DM2_FACEREC_PAD
+#define DM2_FACEREC_PAD 1
+#endif
 struct __attribute__((aligned(16))) FaceRec {
     AAFace aa;          // 32 dwords
     float v[9];         // world-space corners
@@ -19,10 +22,11 @@ struct __attribute__((aligned(16))) FaceRec {
     float opacity, intense;
     int face_id;
     int vid[3];         // vertex ids (backward scatter)
-    float pad[9];       // 272-B stride: records of consecutive entries start 4 LDS banks apart, so lanes that
-                        // read the same field of different records do not collide (256 B would be a 64-way conflict)
+    float pad[DM2_FACEREC_PAD];   // 240-B stride (60 dwords = -4 mod 32 banks): records of consecutive entries start 4 LDS
+                                  // banks apart, so lanes that read the same field of different records do not collide
+                                  // (256 B would be a 64-way conflict; 272 B, +4 banks, behaves the same and costs 32 B more)
 };
-static_assert(sizeof(FaceRec) == 272, "FaceRec must be 272 B");
+static_assert(sizeof(FaceRec) == 236 + 4 * DM2_FACEREC_PAD && sizeof(FaceRec) % 16 == 0, "FaceRec layout");
 
 // Gather entry `face_id` of view `b` into `r` (one lane per record).
 __device__ __forceinline__ void stage_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {

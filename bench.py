@@ -89,7 +89,7 @@ def host_prep_ms(cfg, device, iters=10):
     """Host prep of Renderer.forward (projection + AA tables) forward+backward, reported NEXT TO the metric
     (excluded from `value`): the reference-shaped torch ops vs the fused HIP prep (8(f) rank 1)."""
     import dmesh2_renderer_amd as dm2
-    from dmesh2_renderer_amd import prep
+    from dmesh2_renderer_amd import prep, scenes
     from dmesh2_renderer_amd.pyrenderer import Triangles
     W, H, F, ci = CONFIGS[cfg]
     sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci).to(device)

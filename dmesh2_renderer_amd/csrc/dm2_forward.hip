@@ -106,7 +106,15 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
 
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                            float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
-    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
+    // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list
+    // meets all 256 pixels, so the per-pixel walk below already is the dense formulation (all lanes busy with
+    // the same face) and the pair machinery would only add staging rounds
+#ifdef DM2_QUEUE_AT_TEMP0
+    const bool pairs = true;
+#else
+    const bool pairs = d.aa_temperature > 0.0f;
+#endif
+    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS) && pairs) {
         launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, st);
         return;
     }

@@ -28,13 +28,25 @@ struct TabState {
     uint64_t codes;
 };
 
+// DM2_CLIP_DEFERRED_AREA (default): the corners only go to the LDS table here; the fan area (aa.h:404-413, same
+// triangles in the same order) is summed by the loop that walks the table for the gradient anyway.  The streaming
+// fan (fan_push: cross product, double-literal product and seven selects at each of the 18 emit sites) is the
+// forward kernel's way, which has no table.
+#ifndef DM2_CLIP_DEFERRED_AREA
+#define DM2_CLIP_DEFERRED_AREA 1
+#endif
 __device__ __forceinline__ void tab_push(TabState& S, bool en, float x, float y, uint32_t code, float* polyx, float* polyy) {
     const int slot = S.fan.cnt;
     if (en && slot < MAX_POLY) {
         polyx[slot * POLY_STRIDE] = x; polyy[slot * POLY_STRIDE] = y;
         S.codes |= (uint64_t)code << (4 * slot);
     }
+#if DM2_CLIP_DEFERRED_AREA
+    S.fan.err = S.fan.err || (en && slot >= MAX_POLY);                 // aa.h:45-48 -> error 5
+    S.fan.cnt += en ? 1 : 0;
+#else
     fan_push(S.fan, en, x, y);
+#endif
 }
 
 template <int TI>
@@ -160,6 +172,38 @@ __device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float 
     clip_edge_tab<1>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
     clip_edge_tab<2>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
     if (S.fan.err) return 1;
+#if DM2_CLIP_DEFERRED_AREA
+    const int cnt = S.fan.cnt;
+    if (cnt < 3) return 0;                        // no fan triangle: area 0 (the caller skips it)
+    // one walk over the corners: shoelace gradient of corner i, and the reference's fan triangle (c_0, c_{i-1}, c_i)
+    const float fx = polyx[0], fy = polyy[0];
+    float xm = polyx[(cnt - 1) * POLY_STRIDE], ym = polyy[(cnt - 1) * POLY_STRIDE];   // c_{i-1}
+    float xc = fx, yc = fy;                                                           // c_i   (c_0 == first)
+    float fan_area = 0.f;
+    bool e04 = false;
+#pragma unroll 1
+    for (int i = 0; i < cnt; i++) {
+        const int nxt = (i + 1 == cnt) ? 0 : i + 1;
+        const float xn = polyx[nxt * POLY_STRIDE], yn = polyy[nxt * POLY_STRIDE];
+        const uint32_t code = (uint32_t)((S.codes >> (4 * i)) & 15u);
+        corner_grad_sel(f, code, xc, yc, 0.5f * (yn - ym), 0.5f * (xm - xn), g);
+        if (i >= 2) {
+            const float cr = (xm - fx) * (yc - fy) - (xc - fx) * (ym - fy);
+            const float s_area = (float)(0.5 * (double)cr);                           // aa.h:93
+            e04 = e04 || (s_area < 0);                                                // E04
+            fan_area = fan_area + s_area;
+        }
+        xm = xc; ym = yc; xc = xn; yc = yn;
+    }
+    if (e04) return 1;
+    if (fan_area > pix_area) return 6;
+    area = fan_area;
+    if (area == 0.0f) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = 0.f;
+    }
+    return 0;
+#else
     if (S.fan.area > pix_area) return 6;
     area = S.fan.area;
     const int cnt = S.fan.cnt;
@@ -176,6 +220,7 @@ __device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float 
         xm = xc; ym = yc; xc = xn; yc = yn;
     }
     return 0;
+#endif
 }
 
 }  // namespace dm2

@@ -38,6 +38,7 @@ CONFIGS = {
     "cfg4": (1920, 1080, 1_000_000, 4),
     "cfg2": (512, 512, 50_000, 2),
     "cfg1": (256, 256, 2_000, 1),
+    "cfg5": (3840, 2160, 2_000_000, 5),     # BASELINE configs[4] (quoted on 8 GPUs; fits one MI355X: ~1.3 GB of tensors)
 }
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6.29e12
 

@@ -241,11 +241,15 @@ def main():
     dom_ms = stage_ms.get(dom, 0.0)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     kname = "k_render_backward" if dom == "backward_composite" else "k_render_forward"
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_util = None, None, None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same kernel + config only
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         if tj.get("config") == opt.config and world == 1 and kname in tj:
             traffic = int((tj[kname]["fetch_kb"] + tj[kname]["write_kb"]) * 1024)
+            if "sq_insts_valu" in tj[kname] and dom_ms > 0:
+                # what actually bounds the kernel: share of VALU issue cycles, from the committed
+                # SQ_INSTS_VALU count of this kernel and the launch time measured in this run
+                valu_util = tj[kname]["sq_insts_valu"] * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3)
             traffic_src = "profiles/r01_traffic.json (FETCH_SIZE + WRITE_SIZE, raw; see its note on the gfx950 correction)"
     except (OSError, ValueError, KeyError):
         pass
@@ -253,6 +257,7 @@ def main():
         "bound": "hbm", "kernel": kname,
         "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": round(achieved / (HBM_PEAK / 1e9), 5), "traffic": traffic, "traffic_source": traffic_src,
+        "valu_issue_util": None if valu_util is None else round(valu_util, 4),
         "alg_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_ms, 4),
         "frame_alg_bytes": alg["frame"], "frame_frac": round(alg["frame"] / (ms_step * 1e-3) / HBM_PEAK, 5),
     }

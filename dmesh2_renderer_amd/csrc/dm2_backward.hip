@@ -225,18 +225,23 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                             float* dL_daa_face_verts, hipStream_t st) {
-    // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list
-    // meets all 256 pixels, so the per-pixel walk below already is the dense formulation (all lanes busy with
-    // the same face) and the pair machinery would only add staging rounds
-#ifdef DM2_QUEUE_AT_TEMP0
-    const bool pairs = true;
-#else
-    const bool pairs = d.aa_temperature > 0.0f;
+    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
+        // aa_temperature == 0: no bbox test in the reference (backward.cu:241-244), every face of a tile's list meets
+        // all 256 pixels; the pair enumeration has nothing to prune there -> dm2_backward_point.hip (dense
+        // intersection test per wave, compacted hits for the gradient chain).  -DDM2_POINT_PER_PIXEL: the
+        // reference-shaped per-pixel walk below instead (A/B).
+#ifndef DM2_POINT_PER_PIXEL
+        if (!(d.aa_temperature > 0.0f)) {
+            launch_render_backward_point(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, st);
+            return;
+        }
 #endif
-    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS) && pairs) {
-        launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                     dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
-        return;
+        if (d.aa_temperature > 0.0f) {
+            launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
+            return;
+        }
     }
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);

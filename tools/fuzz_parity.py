@@ -24,7 +24,7 @@ def one_case(rng, idx):
     W, H = int(rng.integers(8, 220)), int(rng.integers(8, 160))
     F = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
     dc = float(rng.choice([0.3, 1.5, 4.0, 12.0, 40.0, 120.0]))
-    temp = float(rng.choice([1.0, 1.0, 0.5, 0.25]))
+    temp = float(rng.choice([1.0, 1.0, 0.5, 0.25, 0.0]))
     K = int(rng.choice([0, 3, 20]))
     cams = int(rng.integers(1, 3))
     sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 1000 + idx, num_cams=cams, shared_verts=bool(rng.integers(0, 2)),

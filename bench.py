@@ -129,6 +129,32 @@ def host_prep_ms(cfg, device, iters=10):
     return res
 
 
+def point_sampled_ms(cfg, device, steps=5):
+    """SURVEY.md 8(d) asks for the aa_temperature = 0 figure next to the headline one: same frame, same faces,
+    point-sampled coverage (no AA), forward+backward ms per step.  Reported in `config`, never in `value`."""
+    global AA_TEMPERATURE
+    from dmesh2_renderer_amd.sharding import BandShardedOp
+    old, AA_TEMPERATURE = AA_TEMPERATURE, 0.0
+    try:
+        args, dLc, dLd, _ = build_inputs(cfg, device, 0, 1)
+    finally:
+        AA_TEMPERATURE = old
+    op = BandShardedOp(args, 1, 0)
+
+    def step():
+        op.forward()
+        op.backward(dLc, dLd)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    return round((time.perf_counter() - t0) / steps * 1e3, 4)
+
+
 def cpu_baseline(args, dLc, dLd, W, H, budget_rows=None):
     """Oracle (CPU port) on a band of the frame: same faces, `rows` pixel rows in the middle."""
     from oracle import cpu as orc
@@ -281,6 +307,8 @@ def main():
         }
         if world == 1 and not opt.no_cpu:
             out["config"]["host_prep_ms_not_in_value"] = host_prep_ms(opt.config, device)
+            if AA_TEMPERATURE == 1.0:
+                out["config"]["ms_per_step_at_aa_temperature_0"] = point_sampled_ms(opt.config, device)
             out["cpu_baseline"] = cpu_baseline(args, dLc, dLd, W, H, opt.cpu_rows)
         else:
             out["cpu_baseline"] = None

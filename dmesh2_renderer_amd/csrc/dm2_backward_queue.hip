@@ -28,8 +28,12 @@
 namespace dm2 {
 
 #ifndef DM2_BQ_CHUNK
-#define DM2_BQ_CHUNK 30      // 3 blocks/CU need <= 54.6 KB LDS (30 faces: 52.3 KB).  A/B at cfg4 on MI355X with TAILMIN 96:
-                             // 28: 2.47 ms, 30: 2.40, 32: 2.40, 33: 2.42, 35 (2 blocks/CU): 3.45
+#define DM2_BQ_CHUNK 24      // 4 blocks/CU need <= 40 KB LDS (24 faces: 38.8 KB, 29 is the most that fits) and <= 128 VGPRs.
+                             // A/B at cfg4 on MI355X, 4 blocks/CU: 20: 2.23 ms, 22: 2.14, 24: 2.13, 26: 2.15, 28: 2.14;
+                             // 3 blocks/CU (153 VGPRs, (x,y) corner table, 30 faces): 2.29
+#endif
+#ifndef DM2_BQ_BLOCKS
+#define DM2_BQ_BLOCKS 4       // resident blocks per CU the register budget is set for (128 VGPRs, 12 B/lane of scratch)
 #endif
 #ifndef DM2_BQ_PAIRCAP
 #define DM2_BQ_PAIRCAP 512
@@ -53,7 +57,7 @@ constexpr uint32_t QB_BLEND = 1u, QB_ACTIVE = 2u;
 struct __attribute__((aligned(16))) BqPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BqPair) == 32, "BqPair");
 
-__global__ void __launch_bounds__(TILE_PIX, 3)
+__global__ void __launch_bounds__(TILE_PIX, DM2_BQ_BLOCKS)
 k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
@@ -72,7 +76,11 @@ k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, con
     __shared__ uint32_t s_queue[4 * BQ_QCAP];                  // survivors: q | face << 8 | corner mask << 14
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk that blend into it in this round
     __shared__ float s_polyx[MAX_POLY * POLY_STRIDE];
+#if !DM2_CLIP_COMPACT_TABLE
     __shared__ float s_polyy[MAX_POLY * POLY_STRIDE];
+#else
+    float* const s_polyy = nullptr;
+#endif
     __shared__ uint32_t s_max_lc;
 
     const int b = blockIdx.z;

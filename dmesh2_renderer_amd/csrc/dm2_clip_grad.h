@@ -138,6 +138,94 @@ __device__ __forceinline__ void corner_grad_sel(const AAFace& f, uint32_t code, 
     rows_add(g, rowb, b0, b1);
 }
 
+// ---- compact corner table ---------------------------------------------------------------------------------
+// A polygon corner is a pixel corner, a triangle vertex or the crossing of a triangle edge with a pixel edge;
+// only a crossing carries a computed coordinate, and only one (the other is the pixel edge's constant).  So the
+// LDS table holds ONE float per corner and a 6-bit code (kind | edge << 2 | aux << 4; aux = pixel edge of a
+// crossing / index of a pixel corner); the walk rebuilds (x, y) -- the same values the reference stores.  Half
+// the LDS of the (x, y) table: what lets a fourth block of the backward kernel live on a CU.
+#ifndef DM2_CLIP_COMPACT_TABLE
+#define DM2_CLIP_COMPACT_TABLE 1
+#endif
+struct CTab { int cnt; bool err; uint64_t codes; };
+
+__device__ __forceinline__ void ctab_push(CTab& S, bool en, float val, uint32_t code6, float* polyv) {
+    const int slot = S.cnt;
+    if (en && slot < MAX_POLY) {
+        polyv[slot * POLY_STRIDE] = val;
+        S.codes |= (uint64_t)code6 << (6 * slot);
+    }
+    S.err = S.err || (en && slot >= MAX_POLY);                         // aa.h:45-48 -> error 5
+    S.cnt += en ? 1 : 0;
+}
+
+template <int TI>
+__device__ __forceinline__ void clip_edge_ctab(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
+                                               uint32_t inside, CTab& S, float* polyv) {
+    constexpr int TJ = (TI + 1) % 3;
+    constexpr uint32_t ecode = (uint32_t)TI << 2;
+    const float p0x = f.v[2 * TI], p0y = f.v[2 * TI + 1], p1x = f.v[2 * TJ], p1y = f.v[2 * TJ + 1];
+    const float ex = f.e[2 * TI], ey = f.e[2 * TI + 1], rx = f.r[2 * TI], ry = f.r[2 * TI + 1];
+    const bool e_vertical = (f.zmask >> (2 * TI)) & 1u, e_horizontal = (f.zmask >> (2 * TI + 1)) & 1u;
+    const bool p0in = (p0x >= pxmin) && (p0x <= pxmax) && (p0y >= pymin) && (p0y <= pymax);
+    const bool p1in = (p1x >= pxmin) && (p1x <= pxmax) && (p1y >= pymin) && (p1y <= pymax);
+    const float tA = (pymin - p0y) * ry, xA = p0x + tA * ex;
+    const float tB = (pxmax - p0x) * rx, yB = p0y + tB * ey;
+    const float tC = (pymax - p0y) * ry, xC = p0x + tC * ex;
+    const float tD = (pxmin - p0x) * rx, yD = p0y + tD * ey;
+    const bool vA = (tA >= 0) && (tA <= 1) && (xA >= pxmin) && (xA <= pxmax) && !e_horizontal;
+    const bool vB = (tB >= 0) && (tB <= 1) && (yB >= pymin) && (yB <= pymax) && !e_vertical;
+    const bool vC = (tC >= 0) && (tC <= 1) && (xC >= pxmin) && (xC <= pxmax) && !e_horizontal;
+    const bool vD = (tD >= 0) && (tD <= 1) && (yD >= pymin) && (yD <= pymax) && !e_vertical;
+    const bool e00 = (vA && ((xA == pxmin) || (xA == pxmax))) || (vB && ((yB == pymin) || (yB == pymax))) ||
+                     (vC && ((xC == pxmin) || (xC == pxmax))) || (vD && ((yD == pymin) || (yD == pymax)));
+    const int n = (int)vA + (int)vB + (int)vC + (int)vD;
+    // first valid crossing in pixel-edge order and the last one: the coordinate that was computed, its t, its pixel edge
+    const float w0 = vA ? xA : (vB ? yB : (vC ? xC : yD));
+    const float t0 = vA ? tA : (vB ? tB : (vC ? tC : tD));
+    const int pe0 = vA ? 0 : (vB ? 1 : (vC ? 2 : 3));
+    const float w1 = vD ? yD : (vC ? xC : yB);
+    const float t1 = vD ? tD : (vC ? tC : tB);
+    const int pe1 = vD ? 3 : (vC ? 2 : 1);
+    const bool two = (n == 2), one = (n == 1), none = (n == 0);
+    const bool sw = two && (t0 > t1);
+    S.err = S.err || e00 || (n > 2) || (one && (p0in == p1in)) || (none && (p0in != p1in));
+    // corners of this edge, in order: [crossing a] [crossing b | end point p1] [pixel corners ...]
+    const bool en1 = two || one || (none && p0in && p1in);
+    const int pea = (two && sw) ? pe1 : pe0;
+    const float wa = (two && sw) ? w1 : w0;
+    const uint32_t ca = (two || one) ? (((pea & 1) ? PK_XV : PK_XH) | ecode | ((uint32_t)pea << 4)) : (PK_TRIV | ecode);
+    ctab_push(S, en1 && !S.err, wa, ca, polyv);
+    const bool en2 = two || (one && !p0in && p1in);
+    const int peb = sw ? pe0 : pe1;
+    const float wb = sw ? w0 : w1;
+    const uint32_t cb = two ? (((peb & 1) ? PK_XV : PK_XH) | ecode | ((uint32_t)peb << 4)) : (PK_TRIV | ecode);
+    ctab_push(S, en2 && !S.err, wb, cb, polyv);
+    // pixel corners inside the triangle, counter-clockwise from the edge's exit (aa.h:359-379)
+    const bool walk = two || (one && p0in && !p1in);
+    const int final_pe = two ? (sw ? pe0 : pe1) : pe0;
+    bool go = walk && !S.err;
+#pragma unroll
+    for (int pvi = 0; pvi < 4; pvi++) {
+        const int cur = (final_pe + 1 + pvi) & 3;
+        go = go && ((inside >> cur) & 1u);
+        ctab_push(S, go, 0.f, PK_CORNER | ((uint32_t)cur << 4), polyv);
+    }
+}
+
+// (x, y) of a table corner
+__device__ __forceinline__ void ctab_xy(const AAFace& f, uint32_t code6, float val, float pxmin, float pxmax, float pymin, float pymax,
+                                        float& x, float& y) {
+    const uint32_t kind = code6 & 3u, aux = code6 >> 4;
+    const int tj = (int)((code6 >> 2) & 3u) == 2 ? 0 : (int)((code6 >> 2) & 3u) + 1;
+    const float vx = tj == 0 ? f.v[0] : (tj == 1 ? f.v[2] : f.v[4]);
+    const float vy = tj == 0 ? f.v[1] : (tj == 1 ? f.v[3] : f.v[5]);
+    const float ex_ = (aux == 1u || aux == 2u) ? pxmax : pxmin;          // pixel corner aux / x of the x = const pixel edge aux (1 or 3)
+    const float ey_ = (aux >= 2u) ? pymax : pymin;                       // pixel corner aux / y of the y = const pixel edge aux (0 or 2)
+    x = kind == PK_XH ? val : (kind == PK_TRIV ? vx : ex_);
+    y = kind == PK_XV ? val : (kind == PK_TRIV ? vy : ey_);
+}
+
 // aa.h:151-441 with Jacobian for a pixel that passed classify_pixel (dm2_clip_area.h) with corner mask `inside`.
 // Returns non-zero on any reference error; area / g valid when 0.
 __device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
@@ -166,6 +254,46 @@ __device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float 
 #ifdef DM2_ABLATE_CLIP
     area = 0.5f * pix_area; return 0;
 #endif
+#if DM2_CLIP_COMPACT_TABLE
+    (void)polyy;
+    CTab S; S.cnt = 0; S.err = false; S.codes = 0;
+    clip_edge_ctab<0>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx);
+    clip_edge_ctab<1>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx);
+    clip_edge_ctab<2>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx);
+    if (S.err) return 1;
+    const int cnt = S.cnt;
+    if (cnt < 3) return 0;                        // no fan triangle: area 0 (the caller skips it)
+    // one walk over the corners: shoelace gradient of corner i, and the reference's fan triangle (c_0, c_{i-1}, c_i)
+    float fx, fy, xm, ym;
+    ctab_xy(f, (uint32_t)(S.codes & 63u), polyx[0], pxmin, pxmax, pymin, pymax, fx, fy);
+    ctab_xy(f, (uint32_t)((S.codes >> (6 * (cnt - 1))) & 63u), polyx[(cnt - 1) * POLY_STRIDE], pxmin, pxmax, pymin, pymax, xm, ym);
+    float xc = fx, yc = fy;                                                           // c_i   (c_0 == first)
+    float fan_area = 0.f;
+    bool e04 = false;
+#pragma unroll 1
+    for (int i = 0; i < cnt; i++) {
+        const int nxt = (i + 1 == cnt) ? 0 : i + 1;
+        float xn, yn;
+        ctab_xy(f, (uint32_t)((S.codes >> (6 * nxt)) & 63u), polyx[nxt * POLY_STRIDE], pxmin, pxmax, pymin, pymax, xn, yn);
+        const uint32_t code = (uint32_t)((S.codes >> (6 * i)) & 15u);
+        corner_grad_sel(f, code, xc, yc, 0.5f * (yn - ym), 0.5f * (xm - xn), g);
+        if (i >= 2) {
+            const float cr = (xm - fx) * (yc - fy) - (xc - fx) * (ym - fy);
+            const float s_area = (float)(0.5 * (double)cr);                           // aa.h:93
+            e04 = e04 || (s_area < 0);                                                // E04
+            fan_area = fan_area + s_area;
+        }
+        xm = xc; ym = yc; xc = xn; yc = yn;
+    }
+    if (e04) return 1;
+    if (fan_area > pix_area) return 6;
+    area = fan_area;
+    if (area == 0.0f) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = 0.f;
+    }
+    return 0;
+#else
     TabState S;
     S.fan.fx = S.fan.fy = S.fan.px = S.fan.py = 0.f; S.fan.area = 0.f; S.fan.cnt = 0; S.fan.err = false; S.codes = 0;
     clip_edge_tab<0>(f, pxmin, pxmax, pymin, pymax, inside, S, polyx, polyy);
@@ -220,6 +348,7 @@ __device__ __forceinline__ int clip_area_grad_classified(const AAFace& f, float 
         xm = xc; ym = yc; xc = xn; yc = yn;
     }
     return 0;
+#endif
 #endif
 }
 

@@ -5,11 +5,11 @@
 // test (backward.cu:241-244): every face of a tile's list is intersected with all 256 pixel rays, and a face
 // contributes to a pixel only where the clamped barycentrics say "inside" (coverage 1, else 0).  That test is
 // cheap and dense; the gradient chain behind it is expensive and sparse (about 4 hits per pixel out of
-// ~250 faces per tile at 1080p / 1 M faces).  Per chunk of 64 staged faces (walked back to front):
+// ~250 faces per tile at 1080p / 1 M faces).  Per chunk of 48 staged faces (walked back to front):
 //
 //   B1  wave w = pixels [64w, 64w+64), ray in registers: for every face of the chunk the intersection +
 //       inside test, one ballot per (face, wave) -> 64-bit hit mask in LDS.  All lanes busy, no divergence.
-//   scan over the 256 (face, wave) hit counts -> every hit gets a slot, face-major.
+//   scan over the 192 (face, wave) hit counts -> every hit gets a slot, face-major.
 // then per round of 256 hits:
 //   B2  lane s: locate its (face, pixel) from the hit masks, recompute the intersection, barycentrics,
 //       colour / depth / alpha -> record in LDS
@@ -26,7 +26,15 @@
 
 namespace dm2 {
 
-constexpr int BP_CHUNK = 64;                 // one mask bit per staged face
+#ifndef DM2_BP_CHUNK
+#define DM2_BP_CHUNK 48      // A/B at cfg4, temperature 0, MI355X: 64 faces / 3 blocks per CU 1.57 ms, 48 / 3: 1.55,
+#endif                       // 48 / 4 (128 VGPRs, 36 B/lane scratch, 36.4 KB LDS): 1.43, 40 / 4: 1.43, 32 / 4: 1.50
+#ifndef DM2_BP_BLOCKS
+#define DM2_BP_BLOCKS 4
+#endif
+constexpr int BP_CHUNK = DM2_BP_CHUNK;       // one mask bit per staged face, one scan thread per (face, wave)
+static_assert(BP_CHUNK <= 64 && BP_CHUNK * 4 <= TILE_PIX, "chunk");
+constexpr int BP_SLOTS = BP_CHUNK * 4;
 constexpr int BP_ACC = 32;
 constexpr int P_DV = 0, P_DC = 9, P_DZ = 18, P_OP = 21, P_IN = 22, P_N = 23, P_FLAG = 31;
 constexpr uint32_t PB_BLEND = 1u, PB_ACTIVE = 2u;
@@ -46,7 +54,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     return pos;
 }
 
-__global__ void __launch_bounds__(TILE_PIX, 3)
+__global__ void __launch_bounds__(TILE_PIX, DM2_BP_BLOCKS)
 k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
@@ -132,8 +140,8 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
         {
             const int cnt = (tid < n * 4) ? __popcll(s_hit[tid]) : 0;             // thread = (face, wave), face-major
             const int ex = block_exclusive_scan(cnt, s_wave, S);
-            s_base[tid] = ex;
-            if (tid == TILE_PIX - 1) s_base[TILE_PIX] = S;
+            if (tid < BP_SLOTS) s_base[tid] = ex;
+            if (tid == TILE_PIX - 1) s_base[BP_SLOTS] = S;
         }
         __syncthreads();
 
@@ -146,7 +154,7 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
             int code = 0;
             bool blend = false;
             if (have) {
-                int lo = 0, hi = TILE_PIX;                                        // s_base[lo] <= s < s_base[hi]
+                int lo = 0, hi = BP_SLOTS;                                        // s_base[lo] <= s < s_base[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (s_base[mid] <= s) lo = mid; else hi = mid;

@@ -57,6 +57,7 @@ def alg_bytes(B, P, F, N, Tn, R):
 
 
 AA_TEMPERATURE = 1.0      # --aa-temperature; 1.0 is the BASELINE workload
+_LAST = {}                # the scene behind the last build_inputs() (host-prep inputs of the multi-GPU step)
 
 
 def build_inputs(cfg, device, rank, world):
@@ -65,6 +66,7 @@ def build_inputs(cfg, device, rank, world):
     from dmesh2_renderer_amd import _C
     W, H, F, ci = CONFIGS[cfg]
     sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci).to(device)
+    _LAST["scene"] = sc
     got = {}
     real = _C.render_forward_cuda
 
@@ -223,8 +225,18 @@ def main():
     dLc_b = dLc[:, op.y0:op.y0 + op.rows].contiguous()
     dLd_b = dLd[:, op.y0:op.y0 + op.rows].contiguous()
 
+    # N > 1: "leaves" (default) all-reduces only the gradients of the leaves -- [dverts | dverts_color | dfaces_opacity
+    # | dfaces_intense], 80 MB at cfg4 -- after pushing this rank's dverts_ndc / daa_face_verts partials through the fused
+    # host-prep backward locally (sharding.BandShardedOp.backward_leaves); "op6" all-reduces the op's six gradient
+    # tensors (140 MB, SURVEY 8(e) as written).  Both leave every rank with the full gradients of the leaves.
+    reduce_mode = os.environ.get("DM2_BENCH_REDUCE", "leaves")
+    sc = _LAST["scene"]
+    prep_inputs = (args[4], args[5], sc.mv[[0]].contiguous(), sc.proj[[0]].contiguous(), W, H)
+
     def step():
         op.forward()
+        if world > 1 and reduce_mode == "leaves":
+            return op.backward_leaves(dLc_b, dLd_b, prep_inputs)
         return op.backward(dLc_b, dLd_b)
 
     def barrier():
@@ -298,7 +310,10 @@ def main():
             "config": {
                 "workload": f"Renderer forward+backward {W}x{H}, {F} triangles (soup, P=3F), B=1, aa_temperature={AA_TEMPERATURE}, K=20, "
                             f"AA visibility gradients on ({'BASELINE configs[3]' if opt.config == 'cfg4' else opt.config})",
-                "sharding": f"tile-row bands x{world}, one all-reduce of packed grads" if world > 1 else "single GPU",
+                "sharding": (f"tile-row bands x{world}, " + ("one all-reduce of the leaf gradients (24P+4F+4BF bytes; dverts_ndc / "
+                                                             "daa_face_verts partials go through the fused prep backward locally)"
+                                                             if reduce_mode == "leaves" else "one all-reduce of the six packed op gradients"))
+                            if world > 1 else "single GPU",
                 "num_rendered_rank0": int(R), "grad_Mtris_per_s": round(F / max(stage_ms.get("backward_composite", 0.0), 1e-9) / 1e3, 2),
                 "stage_ms_rank0": {k: round(v, 4) for k, v in stage_ms.items()},
                 "aa_records_per_pixel_rank0": round(float(tri_cnt.float().mean().item()), 3) if tri_cnt is not None else None,

@@ -11,6 +11,13 @@ frame.  Geometry is replicated.  The forward needs no exchange; the backward
 produces a full-size partial gradient on every rank, packed in ONE fp32 buffer
 (see ``_C.render_backward_cuda``), summed with ONE all-reduce (RCCL over xGMI
 when the process group's backend is ``nccl``; ``gloo`` in the CPU tests).
+
+``BandShardedOp.backward_leaves`` is the cheaper, data-parallel-idiomatic variant: what a training step needs on
+every rank are the gradients of the LEAVES (verts, verts_color, faces_opacity, faces_intense).  ``verts_ndc`` and
+``aa_face_verts`` are intermediates of the host prep; their partial gradients are pushed through the prep's
+backward locally (it is linear in them, so summing over ranks commutes with it) and only
+``[dverts | dverts_color | dfaces_opacity | dfaces_intense]`` crosses the links: 24P + 4F + 4BF bytes instead of
+24P + 12BP + 4F + 28BF (80 MB instead of 140 MB at 1080p / 1 M triangles).
 """
 from __future__ import annotations
 
@@ -111,3 +118,35 @@ class BandShardedOp:
         if reduce and self.world_size > 1:
             grads = allreduce_packed_grads(grads, group)
         return grads
+
+    def backward_leaves(self, dL_dcolor_band, dL_ddepth_band, prep_inputs, group=None, prep_backward=None):
+        """Band gradients -> gradients of the leaves, summed over ranks with ONE all-reduce of 24P + 4F + 4BF bytes.
+
+        ``prep_inputs`` = (verts, faces, mv, proj, width, height) of the host prep that produced ``verts_ndc`` /
+        ``aa_face_verts`` (mv / proj of the rendered cameras, FULL image size).  Returns
+        (dverts, dverts_color, dfaces_opacity, dfaces_intense); dverts includes the contribution that reaches
+        ``verts`` through ``verts_ndc`` and ``aa_face_verts`` (reference: torch autograd through
+        __init__.py:239-262 and pyrenderer.py:6-30; here ``_C.prepare_faces_backward``).
+        """
+        import torch.distributed as dist
+        g = self.backward(dL_dcolor_band, dL_ddepth_band, reduce=False)
+        dverts, dcolor, dopacity, dndc, dintense, daa = g
+        verts, faces, mv, proj, width, height = prep_inputs
+        pb = prep_backward or self._C.prepare_faces_backward
+        dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
+        packed = getattr(dverts, "_dm2_packed", None)
+        n_leaf = dverts.numel() + dcolor.numel() + dopacity.numel()
+        if packed is not None and packed.numel() >= n_leaf + dintense.numel() and dndc.numel() >= dintense.numel():
+            # [dverts | dverts_color | dfaces_opacity] are contiguous at the head of the packed buffer; park
+            # dfaces_intense right behind them (over the no longer needed head of dverts_ndc) -> one contiguous span
+            span = packed[: n_leaf + dintense.numel()]
+            span[n_leaf:].copy_(dintense.reshape(-1))
+            dintense = span[n_leaf:].view(dintense.shape)
+        else:
+            span = torch.cat([dverts.reshape(-1), dcolor.reshape(-1), dopacity.reshape(-1), dintense.reshape(-1)])
+            o1, o2, o3 = dverts.numel(), dverts.numel() + dcolor.numel(), n_leaf
+            dverts, dcolor, dopacity, dintense = (span[:o1].view(dverts.shape), span[o1:o2].view(dcolor.shape),
+                                                  span[o2:o3].view(dopacity.shape), span[o3:].view(dintense.shape))
+        if self.world_size > 1:
+            dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+        return dverts, dcolor, dopacity, dintense

@@ -169,9 +169,15 @@ def _rank_main(rank, world, port, out_dir):
         op = BandShardedOp(args, world, rank)
         color, depth = op.forward()
         g = op.backward(dLc[:, op.y0:op.y0 + op.rows].contiguous(), dLd[:, op.y0:op.y0 + op.rows].contiguous())
+        g = [x.clone() for x in g]
+        # data-parallel variant (what bench.py --gpus N times): only the leaves' gradients are all-reduced
+        sc = b._LAST["scene"]
+        W, H = b.CONFIGS["cfg2"][:2]
+        leaves = op.backward_leaves(dLc[:, op.y0:op.y0 + op.rows].contiguous(), dLd[:, op.y0:op.y0 + op.rows].contiguous(),
+                                    (args[4], args[5], sc.mv[[0]].contiguous(), sc.proj[[0]].contiguous(), W, H))
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), y0=op.y0, rows=op.rows, color=color.cpu().numpy(),
-                 **{f"g{i}": x.cpu().numpy() for i, x in enumerate(g)})
+                 **{f"g{i}": x.cpu().numpy() for i, x in enumerate(g)}, **{f"leaf{i}": x.cpu().numpy() for i, x in enumerate(leaves)})
     finally:
         dist.destroy_process_group()
 
@@ -183,9 +189,17 @@ def test_two_ranks_band_sharded_product_path(tmp_path):
     b = _bench()
     args, dLc, dLd, _ = b.build_inputs("cfg2", torch.device("cuda", 0), 0, 1)
     out, g = _fwd_bwd(args, dLc, dLd)
+    from dmesh2_renderer_amd import _C
+    sc = b._LAST["scene"]
+    W, H = b.CONFIGS["cfg2"][:2]
+    extra = _C.prepare_faces_backward(args[4], args[5], sc.mv[[0]].contiguous(), sc.proj[[0]].contiguous(), W, H,
+                                      g_verts_ndc=g[3], g_aa_face_verts=g[5])
+    leaf_ref = [(g[0] + extra).cpu().numpy(), g[1].cpu().numpy(), g[2].cpu().numpy(), g[4].cpu().numpy()]
     for r in range(world):
         d = np.load(tmp_path / f"r{r}.npz")
         y0, rows = int(d["y0"]), int(d["rows"])
         assert np.array_equal(d["color"], out[1][:, y0:y0 + rows].cpu().numpy())
         for i, name in enumerate(GRADS):
             assert rel_linf(d[f"g{i}"], g[i].cpu().numpy()) <= 1e-5, (r, name)
+        for i, ref in enumerate(leaf_ref):
+            assert rel_linf(d[f"leaf{i}"], ref) <= 1e-5, (r, "leaf", i)

@@ -41,6 +41,12 @@ class OracleBackend:
         return tuple(outs)
 
 
+def oracle_prep_backward(verts, faces, mv, proj, width, height, g_verts_ndc=None, g_aa_face_verts=None):
+    """CPU stand-in for _C.prepare_faces_backward (the product's is GPU only)."""
+    from oracle import cpu as orc
+    return torch.from_numpy(orc.prepare_faces_backward(verts, faces, mv, proj, width, height, g_ndc=g_verts_ndc, g_aa=g_aa_face_verts))
+
+
 def test_band_rows_cover_the_frame():
     for H in (1080, 2160, 100, 16, 7):
         for G in (1, 2, 3, 4, 8):
@@ -67,8 +73,12 @@ def _worker(rank, world, port, W, H, F, seed, out_dir):
         op = BandShardedOp(args, world, rank, backend=OracleBackend())
         color, depth = op.forward()
         grads = op.backward(gc[:, op.y0:op.y0 + op.rows].contiguous(), gd[:, op.y0:op.y0 + op.rows].contiguous())
+        grads = [g.clone() for g in grads]
+        # the data-parallel variant: only the leaves' gradients cross the ranks
+        leaves = op.backward_leaves(gc[:, op.y0:op.y0 + op.rows].contiguous(), gd[:, op.y0:op.y0 + op.rows].contiguous(),
+                                    (sc.verts, sc.faces, sc.mv[[0]], sc.proj[[0]], W, H), prep_backward=oracle_prep_backward)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), y0=op.y0, rows=op.rows, color=color.numpy(), depth=depth.numpy(),
-                 **{f"g{i}": g.numpy() for i, g in enumerate(grads)})
+                 **{f"g{i}": g.numpy() for i, g in enumerate(grads)}, **{f"leaf{i}": g.numpy() for i, g in enumerate(leaves)})
     finally:
         dist.destroy_process_group()
 
@@ -84,6 +94,9 @@ def test_band_sharded_render_equals_full_frame(tmp_path, world):
     gc = rng.randn(1, H, W, 3).astype(np.float32); gd = rng.randn(1, H, W).astype(np.float32)
     gfull = orc.render_backward_cuda(full, gc, gd)
     order = ["verts", "verts_color", "faces_opacity", "verts_ndc", "faces_intense", "aa_face_verts"]
+    leaf_ref = [gfull["verts"] + orc.prepare_faces_backward(sc.verts, sc.faces, sc.mv[[0]], sc.proj[[0]], W, H,
+                                                            g_ndc=gfull["verts_ndc"], g_aa=gfull["aa_face_verts"]),
+                gfull["verts_color"], gfull["faces_opacity"], gfull["faces_intense"]]
     rows = 0
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
@@ -95,4 +108,7 @@ def test_band_sharded_render_equals_full_frame(tmp_path, world):
             ref = gfull[k]
             err = np.abs(d[f"g{i}"] - ref).max() / max(np.abs(ref).max(), 1e-12)
             assert err <= 1e-5, (r, k, err)
+        for i, ref in enumerate(leaf_ref):     # leaf gradients: one all-reduce of 24P + 4F + 4BF bytes
+            err = np.abs(d[f"leaf{i}"] - ref).max() / max(np.abs(ref).max(), 1e-12)
+            assert err <= 1e-5, (r, "leaf", i, err)
     assert rows == H

@@ -28,6 +28,11 @@ namespace dm2 {
 #ifndef DM2_FQ_CHUNK
 #define DM2_FQ_CHUNK 52
 #endif
+#ifndef DM2_FQ_BLOCKS
+#define DM2_FQ_BLOCKS 4       // resident blocks per CU the register budget is set for.  A/B at cfg4 on MI355X: 4 blocks / 52
+                              // faces / 768 pairs / 512 records (38.5 KB, 109 VGPRs) 0.79 ms; 5 blocks (96 VGPRs, no
+                              // spill) need smaller chunks: 36 faces / 384 records 0.91, 30 / 256 0.95; 6 blocks 0.94
+#endif
 #ifndef DM2_FQ_PAIRCAP
 #define DM2_FQ_PAIRCAP 768
 #endif
@@ -51,7 +56,7 @@ constexpr uint32_t QF_BLEND = 2u;    // the face blends into the pixel
 
 struct __attribute__((aligned(8))) FqPair { float alpha, c0, c1, c2, depth; uint32_t flags; };
 
-__global__ void __launch_bounds__(TILE_PIX, 4)
+__global__ void __launch_bounds__(TILE_PIX, DM2_FQ_BLOCKS)
 k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
                        int32_t* __restrict__ out_tri_cnt STAMP_PARAM) {

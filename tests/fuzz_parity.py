@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP path against the CPU oracle (both through the reference's `_C` surface):
 random image sizes, triangle counts, depth complexity, temperature, K, cameras, patch windows and opacities.
-Forward must be bit-exact, gradients within 1e-5 relative L_inf.  `python tools/fuzz_parity.py [seconds] [seed]`.
+Forward must be bit-exact, gradients within 1e-5 relative L_inf.  `python tests/fuzz_parity.py [seconds] [seed]`.
 A development tool (needs a GPU); the fixed cases of tests/test_gpu_parity.py are the gate."""
 import os
 import sys

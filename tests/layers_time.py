@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time LayeredRenderer.generate on BASELINE config 3 (1024x1024, 26^3 Kuhn lattice: T = 93 750 tets,
-F = 191 250 faces, 4 layers) next to the CPU oracle on the same inputs.  `python tools/layers_time.py`."""
+F = 191 250 faces, 4 layers) next to the CPU oracle on the same inputs.  `python tests/layers_time.py [--cpu]`."""
 import os
 import sys
 import time

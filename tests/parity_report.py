@@ -2,7 +2,7 @@
 """Parity report of a library build against the CPU oracle on cfg2 (512x512, 50k triangles):
 max relative L_inf per output / gradient and the flipped-pixel count (pixels whose last contributor or
 AA record count differ).  Used to characterise non-default builds (e.g. -ffp-contract=fast) via
-DM2_HIP_LIB=<path> python tools/parity_report.py."""
+DM2_HIP_LIB=<path> python tests/parity_report.py."""
 import os
 import sys
 

@@ -5,11 +5,14 @@
 // a handful of lanes inside the clipper.  Here the expensive per-(pixel,face)
 // evaluation is decoupled from the per-pixel ordered blend:
 //
-//   A  per staged face: the EXACT set of tile pixels whose unit square passes the
-//      clipper's bounding-box test (aa.h:96-101) is a rectangle; count it, block-scan
-//      the counts -> every (pixel,face) pair of the chunk gets a dense index k.
-//   B  lane k evaluates pair k (all 64 lanes of every wave busy), result -> LDS.
-//   C  each pixel blends ITS pairs in list order (cheap, sequential).
+//   A   per staged face: the EXACT set of tile pixels whose unit square passes the
+//       clipper's bounding-box test (aa.h:96-101) is a rectangle; count it, scan the
+//       counts -> every (pixel,face) pair of the chunk gets a dense index k.
+//   B1  lane k classifies pair k (corner / half-plane tests only); the pairs that survive
+//       are compacted in order into an LDS queue.
+//   B2  one survivor per lane: clip, intersection, shading -> record in LDS.
+//   C   each pixel blends ITS records in list order (cheap, sequential).
+//   (dm2_forward_queue.hip, dm2_backward_queue.hip; the helpers below are the pair index arithmetic.)
 //
 // A pixel outside a face's rectangle contributes exactly nothing in the reference
 // (bbox reject -> oarea 0 -> `continue`), so skipping it is not an approximation.

@@ -94,6 +94,9 @@ __device__ __forceinline__ void clip_edge_area(const AAFace& f, float pxmin, flo
     for (int pvi = 0; pvi < 4; pvi++) {
         const int cur = (final_pe + 1 + pvi) & 3;
         go = go && ((inside >> cur) & 1u);
+        // `go` only ever falls: once no lane of the wave walks on, the remaining corner sites are dead for all of
+        // them (a wave-uniform skip; two or three consecutive inside corners are rare with small triangles)
+        if (__ballot(go) == 0ull) break;
         const float cx = (cur == 1 || cur == 2) ? pxmax : pxmin;
         const float cy = (cur >= 2) ? pymax : pymin;
         fan_push(S, go, cx, cy);

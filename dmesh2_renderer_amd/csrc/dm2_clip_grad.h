@@ -209,6 +209,7 @@ __device__ __forceinline__ void clip_edge_ctab(const AAFace& f, float pxmin, flo
     for (int pvi = 0; pvi < 4; pvi++) {
         const int cur = (final_pe + 1 + pvi) & 3;
         go = go && ((inside >> cur) & 1u);
+        if (__ballot(go) == 0ull) break;          // wave-uniform: no lane walks on (see dm2_clip_area.h)
         ctab_push(S, go, 0.f, PK_CORNER | ((uint32_t)cur << 4), polyv);
     }
 }

@@ -443,7 +443,11 @@ k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, con
                 else if (comp == Q_OP) dst = dL_dfaces_opacity + fc.face_id;
                 else if (comp == Q_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
                 else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - Q_AA);
+#ifdef DM2_ABLATE_FLUSH       // diagnostic only (wrong results): what do the global atomics of the flush cost
+                if (val == 123456.789f) atomicAdd(dst, val);
+#else
                 atomicAdd(dst, val);
+#endif
             }
         }
         STAMP(11)

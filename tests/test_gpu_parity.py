@@ -114,6 +114,8 @@ CASES = [
     dict(W=128, H=128, F=3000, seed=7, temp=1.0, K=20, dc=12.0),          # deep: early termination T < 1e-4
     dict(W=64, H=64, F=20000, seed=8, temp=1.0, K=20, dc=1.5),            # sub-pixel faces: chunks full of 1-4 pixel rectangles
     dict(W=48, H=48, F=40, seed=9, temp=1.0, K=20, dc=60.0),              # huge faces: every face covers whole tiles (pair / survivor cuts)
+    dict(W=48, H=48, F=60, seed=10, temp=0.0, K=20, dc=60.0),             # point sampling, huge faces: several rounds of hits per chunk
+    dict(W=70, H=50, F=2500, seed=11, temp=0.0, K=0, dc=10.0),            # point sampling, many chunks per tile
 ]
 
 

@@ -34,7 +34,9 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        # DM2_ORACLE_LIB: an alternative build of the same sources, e.g. build/libdm2_oracle_asan.so from `make asan`
+        # (run as  LD_PRELOAD=$(g++ -print-file-name=libasan.so) DM2_ORACLE_LIB=... python -m pytest tests -m "not gpu")
+        _LIB = ctypes.CDLL(os.environ.get("DM2_ORACLE_LIB") or build())
         _LIB.orc_binning_create.restype = _c.c_void_p
         _LIB.orc_binning_num_rendered.restype = _c.c_int64
         _LIB.orc_binning_num_rendered.argtypes = [_c.c_void_p]

@@ -3,7 +3,7 @@
 //
 // One 256-thread workgroup per 16x16 tile; each of the 4 waves owns a 16x4 pixel
 // strip.  The tile's sorted face list is consumed in chunks of CHUNK entries;
-// every entry is gathered once into a 256-B LDS record (dm2_stage.h) and read
+// every entry is gathered once into a 240-B LDS record (dm2_stage.h) and read
 // back by the pixel loop with wave-uniform ds_reads.  The forward needs the
 // overlap AREA only (gradients are recomputed by the backward), so the clipper
 // is instantiated without its Jacobian bookkeeping.

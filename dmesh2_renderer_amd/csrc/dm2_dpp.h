@@ -9,11 +9,13 @@ template <int N> __device__ __forceinline__ int dpp_shr_i(int v) { return __buil
 template <int N> __device__ __forceinline__ int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
 template <int N> __device__ __forceinline__ float dpp_shr_f(float v) { return __int_as_float(dpp_shr_i<N>(__float_as_int(v))); }
 // inclusive segmented sum inside a row of 16 lanes; sK = "lane l-K belongs to the same run"
+// (written as "add the shifted value, then keep the sum where the lane continues a run" so that the compiler can fold
+// the DPP move into the add: v_add_f32_dpp + v_cndmask per step instead of v_mov_dpp + v_cndmask + v_add)
 __device__ __forceinline__ void seg_scan16(float& v, bool s1, bool s2, bool s4, bool s8) {
-    float t = dpp_shr_f<1>(v); v += s1 ? t : 0.f;
-    t = dpp_shr_f<2>(v); v += s2 ? t : 0.f;
-    t = dpp_shr_f<4>(v); v += s4 ? t : 0.f;
-    t = dpp_shr_f<8>(v); v += s8 ? t : 0.f;
+    float t = v + dpp_shr_f<1>(v); v = s1 ? t : v;
+    t = v + dpp_shr_f<2>(v); v = s2 ? t : v;
+    t = v + dpp_shr_f<4>(v); v = s4 ? t : v;
+    t = v + dpp_shr_f<8>(v); v = s8 ? t : v;
 }
 
 }  // namespace dm2

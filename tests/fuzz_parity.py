@@ -73,6 +73,8 @@ def main():
         while time.time() - t1 < budget / 2:
             ok, worst, desc = one_case(rng, n)
             n += 1
+            if n % 200 == 0:          # a heartbeat: a long silent GPU run is taken to be hung
+                print(f"... {n} cases, {time.time() - t0:.0f} s, worst so far {max(worst_all, worst):.2e}", flush=True)
             worst_all = max(worst_all, worst)
             if not ok or worst > 1e-5:
                 bad.append((legacy, ok, worst, desc))

@@ -176,7 +176,7 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_s
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
-    dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, st);
+    dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs.hit_masks, bs.hit_valid, st);
     DM2_HIP(hipGetLastError());
     return 0;
 }
@@ -195,7 +195,7 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL
     dm2::BinningState bs = dm2::BinningState::carve(const_cast<void*>(binning_scratch), num_rendered,
                                                     dm2::sort_temp_bytes(num_rendered, Tn));
     dm2::launch_render_backward(*d, is.ranges, bs.face_list, is, dL_dout_color, dL_dout_depth, dL_dverts, dL_dverts_color,
-                                dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
+                                dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs.hit_masks, bs.hit_valid, st);
     DM2_HIP(hipGetLastError());
     return 0;
 }

@@ -224,7 +224,7 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                            float* dL_daa_face_verts, hipStream_t st) {
+                            float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st) {
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         // aa_temperature == 0: no bbox test in the reference (backward.cu:241-244), every face of a tile's list meets
         // all 256 pixels; the pair enumeration has nothing to prune there -> dm2_backward_point.hip (dense
@@ -233,7 +233,7 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
 #ifndef DM2_POINT_PER_PIXEL
         if (!(d.aa_temperature > 0.0f)) {
             launch_render_backward_point(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, st);
+                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, hit_masks, hit_valid, st);
             return;
         }
 #endif

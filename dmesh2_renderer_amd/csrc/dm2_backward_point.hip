@@ -9,6 +9,7 @@
 //
 //   B1  wave w = pixels [64w, 64w+64), ray in registers: for every face of the chunk the intersection +
 //       inside test, one ballot per (face, wave) -> 64-bit hit mask in LDS.  All lanes busy, no divergence.
+//       When the forward of this frame was dm2_forward_point.hip, the masks it stored are simply loaded.
 //   scan over the 192 (face, wave) hit counts -> every hit gets a slot, face-major.
 // then per round of 256 hits:
 //   B2  lane s: locate its (face, pixel) from the hit masks, recompute the intersection, barycentrics,
@@ -59,7 +60,8 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                         float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
-                        float* __restrict__ dL_dfaces_intense) {
+                        float* __restrict__ dL_dfaces_intense, const uint64_t* __restrict__ hit_masks,
+                        const uint32_t* __restrict__ hit_valid) {
     __shared__ FaceRec recs[BP_CHUNK];
     __shared__ float acc[BP_CHUNK * BP_ACC];
     __shared__ BpPair s_pair[TILE_PIX];
@@ -105,6 +107,7 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
 
     const float temp = d.aa_temperature;                           // == 0 (the launcher dispatches on it)
     const float pix_area = 1.0f;
+    const bool use_masks = hit_masks && hit_valid && (hit_valid[0] == 1u);   // written by the matching forward?
     const float bg0 = d.background[0], bg1 = d.background[1], bg2 = d.background[2];
 
     float T = prev_T_final;
@@ -121,19 +124,28 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
         __syncthreads();
 
         // ---- phase B1: which pixels does each face blend into --------------------------------
-        for (int j = 0; j < n; j++) {
-            const FaceRec& fc = recs[j];
-            const uint32_t e = (uint32_t)(total - 1 - base - j);                  // 0-based position in the list
-            bool hit = inside && (e < last_contributor);                          // backward.cu:219-221
-            const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
-            f3 tuv = {0, 0, 0};
-            const bool ok = ray_tri_intersection(ro, rd, p0, p1, p2, tuv);
-            float iuc, ivc; int code;
-            clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
-            const float ratio = mix_coverage(code, 0.0f / pix_area, temp);        // 1 inside, 0 outside at temperature 0
-            hit = hit && ok && (ratio != 0.0f);
-            const unsigned long long bal = __ballot(hit);
-            if (lane == 0) s_hit[j * 4 + wid] = bal;
+        if (use_masks) {
+            // the forward (dm2_forward_point.hip) left one ballot per (list entry, wave): a set bit means the entry
+            // blended into that pixel there, which implies that it lies before the pixel's last contributor
+            if (tid < n * 4) {
+                const int64_t entry = (int64_t)range.x + (uint32_t)(total - 1 - base - (tid >> 2));
+                s_hit[tid] = hit_masks[entry * 4 + (tid & 3)];
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                const FaceRec& fc = recs[j];
+                const uint32_t e = (uint32_t)(total - 1 - base - j);                  // 0-based position in the list
+                bool hit = inside && (e < last_contributor);                          // backward.cu:219-221
+                const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                f3 tuv = {0, 0, 0};
+                const bool ok = ray_tri_intersection(ro, rd, p0, p1, p2, tuv);
+                float iuc, ivc; int code;
+                clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
+                const float ratio = mix_coverage(code, 0.0f / pix_area, temp);        // 1 inside, 0 outside at temperature 0
+                hit = hit && ok && (ratio != 0.0f);
+                const unsigned long long bal = __ballot(hit);
+                if (lane == 0) s_hit[j * 4 + wid] = bal;
+            }
         }
         __syncthreads();
         int S;
@@ -343,11 +355,12 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
 
 void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
-                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense, hipStream_t st) {
+                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                                  const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st) {
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward_point, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense);
+                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, hit_masks, hit_valid);
 }
 
 }  // namespace dm2

@@ -73,9 +73,10 @@ k_emit_keys(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ ke
 }
 
 __global__ void __launch_bounds__(256)
-k_tile_ranges(int64_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+k_tile_ranges(int64_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges, uint32_t* __restrict__ hit_valid) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
+    if (idx == 0) *hit_valid = 0u;          // new lists: the hit masks of an earlier point-sampled forward are stale
     const uint32_t cur = (uint32_t)(keys[idx] >> 32);
     if (idx == 0) ranges[cur].x = 0;
     else {
@@ -143,7 +144,7 @@ void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_dep
                                         (size_t)R, 0u, sort_end_bit(Tn), st);
     }
     StageTimer tm(ST_RANGES, st);
-    hipLaunchKernelGGL(k_tile_ranges, dim3((int)((R + 255) / 256)), dim3(256), 0, st, R, bs.keys, ranges);
+    hipLaunchKernelGGL(k_tile_ranges, dim3((int)((R + 255) / 256)), dim3(256), 0, st, R, bs.keys, ranges, bs.hit_valid);
 }
 
 }  // namespace dm2

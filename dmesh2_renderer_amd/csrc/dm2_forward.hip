@@ -105,19 +105,25 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
 }
 
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                           float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
-    // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list
-    // meets all 256 pixels, so the per-pixel walk below already is the dense formulation (all lanes busy with
-    // the same face) and the pair machinery would only add staging rounds
-#ifdef DM2_QUEUE_AT_TEMP0
-    const bool pairs = true;
-#else
-    const bool pairs = d.aa_temperature > 0.0f;
+                           float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks, uint32_t* hit_valid,
+                           hipStream_t st) {
+    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
+        if (d.aa_temperature > 0.0f) {
+            launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, st);
+            return;
+        }
+        // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list meets
+        // all 256 pixels: the per-pixel walk is the dense formulation there.  dm2_forward_point.hip is that walk with
+        // one extra product: the per-(entry, wave) hit masks the backward would otherwise have to recompute.
+        // -DDM2_POINT_PER_PIXEL: the plain walk below instead (A/B).
+#ifndef DM2_POINT_PER_PIXEL
+        if (hit_masks && hit_valid) {
+            launch_render_forward_point(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, hit_masks, hit_valid, st);
+            return;
+        }
 #endif
-    if (!(d.flags & DM2_FLAG_LEGACY_KERNELS) && pairs) {
-        launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, st);
-        return;
     }
+    // (hit_valid was reset by the binning of this forward, dm2_binning.hip: no masks from this path)
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_FWD, st);
     hipLaunchKernelGGL(k_render_forward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt);

@@ -82,11 +82,16 @@ struct BinningState {
     uint64_t* keys_unsorted;
     uint32_t* face_list_unsorted;
     void* sort_temp; size_t sort_temp_bytes;
+    // aa_temperature == 0 only: per list entry and wave of the tile's block, the 64 pixels the entry blended into in
+    // the forward (dm2_forward_point.hip writes, dm2_backward_point.hip reads); hit_valid[0] == 1 when they are current
+    uint64_t* hit_masks;          // (4 R)
+    uint32_t* hit_valid;          // (1)
     static BinningState carve(void* base, int64_t R, size_t sort_temp_bytes, size_t* total = nullptr) {
         Carver c(base); BinningState s;
         s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
         s.keys_unsorted = c.take<uint64_t>(R); s.face_list_unsorted = c.take<uint32_t>(R);
         s.sort_temp = c.take<char>(sort_temp_bytes); s.sort_temp_bytes = sort_temp_bytes;
+        s.hit_masks = c.take<uint64_t>(4 * R); s.hit_valid = c.take<uint32_t>(1);
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }
@@ -104,8 +109,12 @@ void launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* pa
 void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
                      uint2* ranges, hipStream_t st);
 
+void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
+                                 uint32_t* hit_valid, hipStream_t st);
 void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                           float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
+                           float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks, uint32_t* hit_valid,
+                           hipStream_t st);
 void launch_prepare_faces(const dm2_prep_desc& d, hipStream_t st);
 void launch_prepare_faces_backward(const dm2_prep_desc& d, const float* g_ndc, const float* g_image, const float* g_aa,
                                    float* image_grad_scratch, float* g_verts, hipStream_t st);
@@ -113,7 +122,8 @@ void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, 
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
 void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
-                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense, hipStream_t st);
+                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                                  const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
 void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
@@ -121,7 +131,7 @@ void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges,
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                            float* dL_daa_face_verts, hipStream_t st);
+                            float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
 void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,
                    LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
 

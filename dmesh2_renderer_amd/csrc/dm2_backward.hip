@@ -238,8 +238,21 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
         }
 #endif
         if (d.aa_temperature > 0.0f) {
+            // Two launches, one of which returns at once (decided on the device by hit_valid, no host read-back): when this
+            // frame's forward left its blend masks, dm2_backward_mask.hip uses them; otherwise dm2_backward_queue.hip
+            // enumerates and classifies the pairs itself.  -DDM2_BWD_NO_MASKS: always the latter (A/B).
+            StageTimer tm(ST_BWD, st);
+#ifndef DM2_BWD_NO_MASKS
+            if (hit_masks && hit_valid) {
+                launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                            dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
+                launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                             dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid, st);
+                return;
+            }
+#endif
             launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, st);
+                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, nullptr, st);
             return;
         }
     }

@@ -62,7 +62,9 @@ k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, con
                         ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                         float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                         float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
-                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts STAMP_PARAM) {
+                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts,
+                        const uint32_t* __restrict__ hit_valid STAMP_PARAM) {
+    if (hit_valid && hit_valid[0] == 2u) return;      // the forward left blend masks: dm2_backward_mask.hip does this frame
     __shared__ FaceRec recs[BQ_CHUNK];
     __shared__ float acc[BQ_CHUNK * BQ_ACC];
     __shared__ BqPair s_pair[TILE_PIX];
@@ -458,11 +460,11 @@ k_render_backward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, con
 void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                  float* dL_daa_face_verts, hipStream_t st) {
+                                  float* dL_daa_face_verts, const uint32_t* hit_valid, hipStream_t st) {
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
-    StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts STAMP_ARG(1));
+                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
+                       hit_valid STAMP_ARG(1));
 }
 
 }  // namespace dm2

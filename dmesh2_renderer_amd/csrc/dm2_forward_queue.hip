@@ -59,7 +59,8 @@ struct __attribute__((aligned(8))) FqPair { float alpha, c0, c1, c2, depth; uint
 __global__ void __launch_bounds__(TILE_PIX, DM2_FQ_BLOCKS)
 k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
-                       int32_t* __restrict__ out_tri_cnt STAMP_PARAM) {
+                       int32_t* __restrict__ out_tri_cnt, uint64_t* __restrict__ hit_masks,
+                       uint32_t* __restrict__ hit_valid STAMP_PARAM) {
     __shared__ FaceRec recs[FQ_CHUNK];
     __shared__ FqPair s_pair[FQ_SURVCAP];
     __shared__ float s_ray[TILE_PIX * 6];
@@ -71,6 +72,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ uint16_t s_slot[FQ_PAIRCAP];              // per pair: survivors before it within its wave's range
     __shared__ uint32_t s_queue[4 * FQ_QCAP];            // survivors: q | face << 8 | corner mask << 14
     __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
+    __shared__ unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -78,6 +80,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     STAMP_DECL
     fill_inv_table(s_inv);
     s_mask[tid] = 0;
+    if (hit_valid && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) hit_valid[0] = 2u;   // AA blend masks are current
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -123,6 +126,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
             s_rect[tid] = rect;
         }
+        if (tid < FQ_CHUNK * 4) s_bmask[tid] = 0;
         STAMP(2)
         if (wid == 0) {                                             // a chunk is at most 64 faces: all staging lanes are in wave 0
             const int inc = wave_inclusive_scan(cnt);
@@ -237,10 +241,14 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             if (out.flags) {
                 s_pair[s] = out;
                 atomicOr(&s_mask[q], 1ull << j);
+                if (out.flags & QF_BLEND) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
             }
         }
         STAMP(5)
         __syncthreads();
+        // what the backward needs to find its work without re-classifying (dm2_backward_mask.hip): per list entry and
+        // wave of the tile's block, the pixels the entry blends into
+        if (hit_masks && tid < n * 4) hit_masks[((int64_t)range.x + base + (tid >> 2)) * 4 + (tid & 3)] = s_bmask[tid];
 
         // ---- phase C: ordered blend of this pixel's records ---------------------------------
         {
@@ -281,10 +289,12 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 }
 
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st) {
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
+                                 uint32_t* hit_valid, hipStream_t st) {
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_FWD, st);
-    hipLaunchKernelGGL(k_render_forward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt STAMP_ARG(0));
+    hipLaunchKernelGGL(k_render_forward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt,
+                       hit_masks, hit_valid STAMP_ARG(0));
 }
 
 }  // namespace dm2

@@ -119,7 +119,8 @@ void launch_prepare_faces(const dm2_prep_desc& d, hipStream_t st);
 void launch_prepare_faces_backward(const dm2_prep_desc& d, const float* g_ndc, const float* g_image, const float* g_aa,
                                    float* image_grad_scratch, float* g_verts, hipStream_t st);
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, hipStream_t st);
+                                 float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
+                                 uint32_t* hit_valid, hipStream_t st);
 void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
@@ -127,7 +128,11 @@ void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges,
 void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                  float* dL_daa_face_verts, hipStream_t st);
+                                  float* dL_daa_face_verts, const uint32_t* hit_valid, hipStream_t st);
+void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
+                                 float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                                 float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,

@@ -24,6 +24,7 @@
 #include "dm2_dpp.h"
 #include "dm2_pairs.h"
 #include "dm2_stage.h"
+#include "dm2_stamps.h"
 #include "dm2_state.h"
 
 namespace dm2 {
@@ -58,7 +59,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                        float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                        float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
                        float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts,
-                       const uint64_t* __restrict__ hit_masks, const uint32_t* __restrict__ hit_valid) {
+                       const uint64_t* __restrict__ hit_masks, const uint32_t* __restrict__ hit_valid STAMP_PARAM) {
     if (hit_valid[0] != 2u) return;                                // the masks are not this frame's: the queue kernel runs
 
     __shared__ FaceRec recs[BM_CAND];
@@ -75,6 +76,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    STAMP_DECL
     s_mask[tid] = 0;
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
@@ -117,9 +119,11 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_recd = 0.f;
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
 
+    STAMP(0)
     int n = 0;
     for (int base = 0; base < total; base += n) {
         __syncthreads();                                            // previous chunk flushed, LDS reusable
+        STAMP(1)
         const int nc = min(BM_CAND, total - base);
         // recs[j] / s_hit[j][.] = entry (total-1) - (base+j): back to front (backward.cu:171)
         if (tid < nc * 4) {
@@ -128,7 +132,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
         if (tid < nc) stage_face(d, b, (int)face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
         for (int k = tid; k < nc * BM_ACC; k += TILE_PIX) acc[k] = 0.f;
+        STAMP(2)
         __syncthreads();
+        STAMP(3)
         int Sall;
         {
             const int cnt = (tid < nc * 4) ? __popcll(s_hit[tid]) : 0;            // thread = (face, wave), face-major
@@ -147,6 +153,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             n = lo;
         }
         const int S = s_base[4 * n];
+        STAMP(4)
 
         // ---- phase B2: one blending (pixel,face) pair per lane -------------------------------
         const bool have = tid < S;
@@ -201,7 +208,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             s_pair[tid] = out;
             if (blend) atomicOr(&s_mask[q], 1ull << j);
         }
+        STAMP(5)
         __syncthreads();
+        STAMP(6)
 
         // ---- phase C: per-pixel back-to-front replay ------------------------------------------
         {
@@ -244,7 +253,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 pr.c0 = dLc0; pr.c1 = dLc1; pr.c2 = dLc2; pr.depth = dLd;
             }
         }
+        STAMP(7)
         __syncthreads();
+        STAMP(8)
 
         // ---- phase D: chain rule + per-entry accumulation (see dm2_backward_queue.hip) ----------
         {
@@ -347,7 +358,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 }
             }
         }
+        STAMP(9)
         __syncthreads();
+        STAMP(10)
 
         // ---- flush: lane = (entry, component); 8 entries per pass ------------------------------
         const int comp = tid & 31;
@@ -367,7 +380,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 atomicAdd(dst, val);
             }
         }
+        STAMP(11)
     }
+    STAMP_FLUSH
 }
 
 void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
@@ -377,7 +392,7 @@ void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, 
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     hipLaunchKernelGGL(k_render_backward_mask, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
                        dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
-                       hit_masks, hit_valid);
+                       hit_masks, hit_valid STAMP_ARG(1));
 }
 
 }  // namespace dm2

@@ -10,6 +10,10 @@ and records
                       reference's scalar Python AA oracle, both flavours
                       (pyrenderer.py:66-205 autograd, :207-425 analytic), plus
                       the per-triangle tables ``Triangles`` builds (:6-30).
+  aa_error_pairs.npz  the same fields for inputs found by a seeded search near the clipper's tie cases: at
+                      least 8 inputs for each of the reference's exceptions "Error code 00" .. "05"
+                      (pyrenderer.py:274,294,364,380,391,423), labelled by the message the reference printed,
+                      plus near-tie inputs it accepts.
   boundary_*.npz      the exact 21 positional arguments the reference hands to
                       ``_C.render_forward_cuda`` (__init__.py:48-78) for small
                       seeded scenes, the final ``(color, depth)`` post-map
@@ -126,10 +130,99 @@ def aa_cases(rng):
     return cases
 
 
-def make_aa(ref):
+def aa_error_candidates(rng):
+    """Endless stream of (tri, pixmin, family) near the clipper's tie cases: families aimed at the reference's
+    exceptions E00-E05 (pyrenderer.py:274,294,364,380,391,423 <-> aa.h:265,301,325,355,398/411,437)."""
+    def jit(x, k=3):             # move a float32 by up to k ulps
+        x = np.float32(x)
+        for _ in range(rng.randint(0, k + 1)):
+            x = np.nextafter(x, np.float32(np.inf) if rng.rand() < 0.5 else np.float32(-np.inf))
+        return x
+    it = 0
+    while True:
+        fam = it % 7
+        it += 1
+        if fam == 6:
+            # E01: a long edge past a pixel corner at small coordinates: the rounding of t * e (|e| ~ 100) exceeds the
+            # ulp of the crossing, so the crossings with BOTH pixel edges at that corner can test valid
+            pm = rng.randint(1, 8, size=2).astype(np.float32)
+            cx, cy = pm[0] + rng.randint(0, 2), pm[1] + rng.randint(0, 2)
+            d = rng.uniform(-1, 1, 2); d /= np.linalg.norm(d)
+            L = rng.uniform(10, 300)
+            nrm = np.array([-d[1], d[0]])
+            off = nrm * rng.uniform(-2e-6, 2e-6)
+            a = np.array([cx, cy]) + off - d * L * rng.uniform(0.2, 1); b = np.array([cx, cy]) + off + d * L * rng.uniform(0.2, 1)
+            c = np.array([cx, cy]) + nrm * rng.uniform(1, 40) * rng.choice([-1, 1])
+            yield np.array([a, b, c], np.float32), pm, fam
+            continue
+        pm = rng.randint(2, 60, size=2).astype(np.float32)
+        cx, cy = pm[0] + rng.randint(0, 2), pm[1] + rng.randint(0, 2)       # a pixel corner
+        if fam == 0:      # edge through (almost) a pixel corner, generic direction            -> E00, E04, E05
+            d = rng.uniform(-1, 1, 2); d /= np.linalg.norm(d)
+            a = np.array([cx, cy]) - d * rng.uniform(0.5, 4); b = np.array([cx, cy]) + d * rng.uniform(0.5, 4)
+            a = [jit(a[0]), jit(a[1])]; b = [jit(b[0]), jit(b[1])]
+            c = np.array([cx, cy]) + np.array([-d[1], d[0]]) * rng.uniform(1, 4) * rng.choice([-1, 1])
+            tri = [a, b, c]
+        elif fam == 1:    # near-vertical edge (|e.x| < 1e-3: "iszero") across an x = const pixel edge   -> E02, E03
+            x = cx + rng.uniform(-5e-4, 5e-4); dx = rng.uniform(-9e-4, 9e-4)
+            tri = [[x, pm[1] + rng.uniform(-2, 0.9)], [x + dx, pm[1] + rng.uniform(0.1, 3)],
+                   [x + rng.uniform(1, 4) * rng.choice([-1, 1]), pm[1] + rng.uniform(-1, 2)]]
+        elif fam == 2:    # near-horizontal edge across a y = const pixel edge                  -> E02, E03
+            y = cy + rng.uniform(-5e-4, 5e-4); dy = rng.uniform(-9e-4, 9e-4)
+            tri = [[pm[0] + rng.uniform(-2, 0.9), y], [pm[0] + rng.uniform(0.1, 3), y + dy],
+                   [pm[0] + rng.uniform(-1, 2), y + rng.uniform(1, 4) * rng.choice([-1, 1])]]
+        elif fam == 3:    # sliver hugging a pixel edge                                           -> E00, E03, E04
+            y = cy + rng.uniform(-2e-6, 2e-6)
+            tri = [[pm[0] - rng.uniform(0.2, 2), jit(y)], [pm[0] + 1 + rng.uniform(0.2, 2), jit(y)],
+                   [pm[0] + rng.uniform(0, 1), jit(y + rng.uniform(-3e-6, 3e-6))]]
+        elif fam == 4:    # triangle corner (almost) on a pixel corner                            -> E00, E04, E05
+            tri = [[jit(cx), jit(cy)], [cx + rng.uniform(-3, 3), cy + rng.uniform(-3, 3)], [cx + rng.uniform(-3, 3), cy + rng.uniform(-3, 3)]]
+        else:             # edge along the pixel diagonal through two corners
+            tri = [[jit(pm[0] - 1), jit(pm[1] - 1)], [jit(pm[0] + 2), jit(pm[1] + 2)], [pm[0] + rng.uniform(-3, 3), pm[1] + rng.uniform(2, 5)]]
+        yield np.array(tri, np.float32), pm, fam
+
+
+def aa_error_cases(ref, per_code=8, seed=4321):
+    """Search the candidate stream for inputs on which the reference's analytic clipper raises each of
+    "[pyrasterizer] Error code 00" .. "05" (the message it prints is the label); ``per_code`` inputs per code,
+    plus, per family, the same number of near-tie inputs it accepts.  The search calls the reference only."""
+    import contextlib
+    import io
     pr = ref.pyrenderer
-    rng = np.random.RandomState(1234)
-    cases = aa_cases(rng)
+    rng = np.random.RandomState(seed)
+    want = {"[pyrasterizer] Error code %02d" % k: per_code for k in range(6)}
+    ok_left = {fam: per_code for fam in range(7)}
+    cases = []
+    tried = 0
+    for tri, pm, fam in aa_error_candidates(rng):
+        tried += 1
+        if tried > 400000 or (not any(want.values()) and not any(ok_left.values())):
+            break
+        if fam != 6 and not any(want[m] for m in want if not m.endswith("01")) and not ok_left[fam]:
+            continue
+        tv = torch.from_numpy(tri.copy()).unsqueeze(0)
+        tris = pr.Triangles(tv[:, 0], tv[:, 1], tv[:, 2])
+        pixs = pr.Pixels(torch.from_numpy(pm).unsqueeze(0), torch.from_numpy(pm + 1.0).unsqueeze(0))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pr.tri_pixel_overlap_area(tris, pixs, 0, 0, use_autograd=False)
+        msg = buf.getvalue().strip()
+        if msg:
+            if want.get(msg, 0) > 0:
+                want[msg] -= 1
+                cases.append((tri, pm))
+        elif ok_left[fam] > 0:
+            ok_left[fam] -= 1
+            cases.append((tri, pm))
+    missing = {m: k for m, k in want.items() if k}
+    assert not missing, f"no input found for {missing} in {tried} candidates"
+    return cases
+
+
+def make_aa(ref, cases=None, name="aa_pairs.npz"):
+    pr = ref.pyrenderer
+    if cases is None:
+        cases = aa_cases(np.random.RandomState(1234))
     n = len(cases)
     tri_in = np.stack([c[0] for c in cases]).astype(np.float32)     # (n,3,2) as given
     pixmin = np.stack([c[1] for c in cases]).astype(np.float32)     # (n,2)
@@ -211,8 +304,9 @@ def make_aa(ref):
     out.update(area_analytic=area_an, grad_analytic=grad_an, err_analytic=err_an,
                area_autograd=area_ag, grad_autograd=grad_ag, err_autograd=err_ag,
                npoly=npoly, msg_analytic=np.array(msg_an))
-    np.savez_compressed(os.path.join(HERE, "aa_pairs.npz"), **out)
-    print("aa_pairs:", n, "cases; errors", int(err_an.sum()), "partial", int(((area_an > 0) & (area_an < 1)).sum()))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, ":", n, "cases; errors", int(err_an.sum()), "partial", int(((area_an > 0) & (area_an < 1)).sum()),
+          "messages", dict(zip(*np.unique(np.array(msg_an), return_counts=True))))
 
 
 # --------------------------------------------------------------------------
@@ -286,7 +380,11 @@ def make_layers_boundary(ref, stub, scenes):
 def main():
     scenes = load_scenes()
     ref, stub = import_reference()
+    if "--only-aa-errors" in sys.argv:
+        make_aa(ref, aa_error_cases(ref), "aa_error_pairs.npz")
+        return
     make_aa(ref)
+    make_aa(ref, aa_error_cases(ref), "aa_error_pairs.npz")
     make_boundary(ref, stub, scenes, "boundary_full.npz", 48, 32, 60, scenes.SEED_BASE + 11,
                   cams=2, batch_idx=[0, 1], patch_min=[[0, 0], [0, 0]], pw=48, ph=32, temp=1.0, K=20)
     make_boundary(ref, stub, scenes, "boundary_patch.npz", 48, 32, 60, scenes.SEED_BASE + 12,

@@ -104,3 +104,32 @@ def test_aa_gradient_finite_difference_f64():
         assert np.allclose(grad, fd, atol=1e-5), (grad, fd)
         checked += 1
     assert checked >= 25
+
+
+# ---- the reference's exceptions E00..E05 (tests/golden/aa_error_pairs.npz) -------------------------------------
+@pytest.fixture(scope="module")
+def ge(golden_dir):
+    return np.load(os.path.join(golden_dir, "aa_error_pairs.npz"))
+
+
+def test_error_vectors_cover_every_code(ge):
+    msgs = list(ge["msg_analytic"])
+    for k in range(6):
+        assert msgs.count("[pyrasterizer] Error code %02d" % k) >= 5, k
+    assert msgs.count("") >= 30                      # near-tie inputs the reference accepts
+
+
+def test_error_codes_match_reference(ge):
+    """Reference exception "Error code 0k" (pyrenderer.py:274,294,364,380,391,423) <-> native code k+1
+    (aa.h:265,301,325,355,398/411,437); accepted near-tie inputs give the reference's area and gradient."""
+    t = _tables(ge)
+    assert np.array_equal(orc.aa_tables(ge["tri_in"], np.float32)["verts"], ge["t_verts"])
+    for i in range(len(ge["pixmin"])):
+        area, grad, code = orc.aa_overlap(t, i, ge["pixmin"][i], np.float32)
+        msg = str(ge["msg_analytic"][i])
+        if msg:
+            assert code == int(msg[-2:]) + 1, (i, msg, code)
+            continue
+        assert code == 0, (i, code)
+        assert abs(area - ge["area_analytic"][i]) <= 2e-6, (i, area, ge["area_analytic"][i])
+        assert np.allclose(grad, ge["grad_analytic"][i], rtol=1e-5, atol=2e-6), (i, grad, ge["grad_analytic"][i])

@@ -17,6 +17,9 @@ import bench  # noqa: E402
 
 FWDQ = ["prologue", "top barrier", "stage faces", "scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
         "barrier + phase C (blend)", "epilogue"]
+BWDM = ["prologue", "top barrier", "mask load + stage faces + zero acc (issue)", "barrier: wait for the gather", "scan + barrier + cut",
+        "phase B2 (decode, clip+grad, shade)", "barrier after B2", "phase C (replay)", "barrier after C",
+        "phase D (chain + dpp + lds atomics)", "barrier after D", "flush atomics"]
 BWDQ = ["prologue", "top barrier", "stage faces", "zero+scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
         "barrier + phase C (replay)", "-", "barrier after C", "phase D (chain+dpp+lds atomics)", "barriers before flush", "flush atomics"]
 
@@ -36,7 +39,7 @@ def main():
     torch.cuda.synchronize()
     n = lib.dm2_debug_stamps(buf, 32, 1)
     assert n == 32, n
-    for name, labels, off in (("forward", FWDQ, 0), ("backward", BWDQ, 16)):
+    for name, labels, off in (("forward", FWDQ, 0), ("backward", BWDM if os.environ.get("DM2_STAMP_BWD", "mask") == "mask" else BWDQ, 16)):
         vals = [buf[off + i] for i in range(16)]
         tot = sum(vals)
         print(f"{name}: total wave-cycles {tot:.3e}")

@@ -73,12 +73,13 @@ EXPORTS = {
     "dm2_scratch_bytes": (_sz, [ctypes.c_int, _i64, _i64]),
     "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
     "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
-    "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz,
+    "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
     "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dm2_prepare_faces": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp]),
     "dm2_prepare_faces_backward": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dm2_debug_aa_overlap": (ctypes.c_int, [ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
     "dm2_profile_enable": (None, [ctypes.c_int]),
     "dm2_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
@@ -116,7 +117,7 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dm2_abi_version() != 1:
+        if lib.dm2_abi_version() != 2:
             raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
         if path is None:
             _lib = lib
@@ -265,7 +266,7 @@ def render_forward_cuda(*args):
             e = _bytes(dev, 0)
             return 0, color, depth, oarea, tri_id, tri_cnt, doarea, e, _bytes(dev, 0), _bytes(dev, 0)
         tri_cnt = torch.empty((B, H, W), dtype=i32, device=dev)
-        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 0))
+        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 1))
         img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_IMAGE, N, Tn))
         nr = _i64(0)
         if lib.dm2_forward_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr)):
@@ -306,7 +307,8 @@ def render_backward_cuda(*args):
             raise RuntimeError("dL_dout_color / dL_dout_depth must have dimensions (B, H, W, 3) / (B, H, W)")
         dc = _c(dL_dcolor, f32); dd = _c(dL_ddepth, f32)
         with torch.cuda.device(dev):
-            if lib.dm2_backward(ctypes.byref(d), num_rendered, _ptr(dc), _ptr(dd), _ptr(bin_buf), bin_buf.numel(),
+            if lib.dm2_backward(ctypes.byref(d), num_rendered, _ptr(dc), _ptr(dd), _ptr(face_buf), face_buf.numel(),
+                                _ptr(bin_buf), bin_buf.numel(),
                                 _ptr(img_buf), img_buf.numel(), _ptr(g_verts), _ptr(g_color), _ptr(g_opac),
                                 _ptr(g_ndc), _ptr(g_int), _ptr(g_aa), _stream(dev)):
                 raise _err(lib, "render_backward_cuda")
@@ -444,3 +446,20 @@ def debug_fetch(what, count, aux, num_rendered, scratch, dtype, n):
         if lib.dm2_debug_fetch(what, count, aux, num_rendered, _ptr(scratch), scratch.numel(), _ptr(out), _stream(scratch.device)):
             raise _err(lib, "debug_fetch")
     return out
+
+
+def debug_aa_overlap(variant, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, pixmin):
+    """Run device clipper `variant` (see dm2_debug_aa_overlap) on n (triangle, pixel) pairs; tables (n,3,2) / (n,3),
+    pixmin (n,2).  -> area (n), grad (n,3,2), code (n) int32."""
+    lib = load_library()
+    dev = _require_gpu(aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, pixmin)
+    f32 = torch.float32
+    n = aa_v.shape[0]
+    ts = [_c(aa_v, f32), _c(aa_e, f32), _c(aa_z, torch.bool), _c(aa_r, f32), _c(aa_n, f32), _c(aa_c, f32), _c(pixmin, f32)]
+    area = torch.zeros((n,), dtype=f32, device=dev)
+    grad = torch.zeros((n, 3, 2), dtype=f32, device=dev)
+    code = torch.zeros((n,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        if lib.dm2_debug_aa_overlap(int(variant), n, *[_ptr(t) for t in ts], _ptr(area), _ptr(grad), _ptr(code), _stream(dev)):
+            raise _err(lib, "debug_aa_overlap")
+    return area, grad, code

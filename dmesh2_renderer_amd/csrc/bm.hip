@@ -15,23 +15,24 @@
 //   flush with (entry,component) global atomics.
 //
 // Memory pipeline.  A chunk's inputs -- face ids, blend masks, packed face records (dm2_stage.h: 256 B per
-// (view,face), two full lines) -- are requested ONE CHUNK AHEAD, right after the current chunk's cut is known, with
-// LDS-direct loads (global_load_lds_dwordx4: 4 records per wave instruction, no staging registers) into the OTHER
-// half of double-buffered LDS arrays: the global latency is covered by phase B2 of the current chunk instead of
-// stalling the block (in-kernel stamps of the round-1 kernel: 48 % of a block's time went into that stall).  The ids
-// a record address needs are read one chunk earlier still, as a window of 64 entries.
+// (view,face), two full lines) -- are requested ONE CHUNK AHEAD, right after the current chunk's cut is known, by
+// all 256 threads (16 lanes x 16 B per record) into registers, and stored to the OTHER half of double-buffered LDS
+// arrays after phase C (before phase D, where the register pressure peaks): the global latency is covered by phases
+// B2 and C of the current chunk instead of stalling the block (in-kernel stamps of the round-1 kernel: 48 % of a
+// block's time went into that stall).  The ids a record address needs are read one chunk earlier still, as a window
+// of 64 entries.
 //
 // The masks are only valid when this frame's forward was dm2_forward_queue.hip (hit_valid[0] == 2); otherwise the
 // kernel returns at once and k_render_backward, launched behind it, does the work.
 #include <hip/hip_runtime.h>
 
-#include "dm2_clip_seg.h"
-#include "dm2_device_math.h"
-#include "dm2_dpp.h"
-#include "dm2_pairs.h"
-#include "dm2_stage.h"
-#include "dm2_stamps.h"
-#include "dm2_state.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_clip_seg.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_device_math.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_dpp.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_pairs.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_stage.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_stamps.h"
+#include "../../dmesh2_renderer_amd/csrc/dm2_state.h"
 
 namespace dm2 {
 
@@ -45,16 +46,6 @@ constexpr int REC_CHUNKS = (int)(sizeof(FaceRec) / 16);   // 15 x 16 B of the 25
 
 struct __attribute__((aligned(16))) BmPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BmPair) == 32, "BmPair");
-
-// LDS-direct loads: lane l's 16 (4) bytes at `gsrc` land at lds_base + 16 (4) * l; lds_base must be wave-uniform
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
-}
 
 // index of the n-th (0-based) set bit of m; n < popcount(m)
 __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
@@ -72,12 +63,7 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
     return pos + (up ? 32 : 0);
 }
 
-#ifndef DM2_BM_BLOCKS
-#define DM2_BM_BLOCKS 3       // resident blocks per CU the register budget is set for.  A/B at cfg4 on MI355X: 4 blocks (128 VGPRs) spill
-                              // 39 registers to scratch, and a scratch reload waits for every LDS-direct load issued before it: 2.08 ms;
-                              // 3 blocks (no spill) 1.63 ms
-#endif
-__global__ void __launch_bounds__(TILE_PIX, DM2_BM_BLOCKS)
+__global__ void __launch_bounds__(TILE_PIX, 4)
 k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                        float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
@@ -148,31 +134,36 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
 
     // ---- the walk's position k (0 = the tile's deepest live entry) maps to list entry range.x + total - 1 - k
-    // (backward.cu:171).  The next chunk's inputs go straight from global memory into the other LDS buffer
-    // (global_load_lds: per-lane source address, destination = wave-uniform base + lane * size; no registers held).
+    // (backward.cu:171).  Prefetch registers: what this thread holds of the NEXT chunk.
+    const int rslot = tid >> 4, rpart = tid & 15;                  // record copy: records rslot, 16 + rslot; 16-byte part
+    uint4 pre_rec0 = make_uint4(0, 0, 0, 0), pre_rec1 = make_uint4(0, 0, 0, 0);
+    unsigned long long pre_hit = 0;                                // tid < 128: mask (face tid >> 2, wave tid & 3)
+    uint32_t pre_id = 0;                                           // tid < 64: id of walk position (next base) + tid
     auto walk_entry = [&](int k) -> int64_t { return (int64_t)range.x + (uint32_t)(total - 1 - k); };
-    const int rl = lane / REC_CHUNKS, rp = lane - rl * REC_CHUNKS;   // record copy: 4 records x 15 parts per wave instruction
-    // request the id window [nb, nb + 64) of the walk into s_ids2[buf]
-    auto request_ids = [&](int buf, int nb) {
-        if (wid == 2 && nb + lane < total)
-            glds4(face_list + walk_entry(nb + lane), &s_ids2[buf][0]);
-    };
-    // request masks + records of the chunk starting at walk position nb into buffer buf; ids[i]: face id of position nb + i
-    auto request_chunk = [&](int buf, int nb, const uint32_t* ids) {
+    // request masks + records of the chunk starting at walk position nb; ids[i]: face id of walk position nb + i
+    auto request_chunk = [&](int nb, const uint32_t* ids) {
         const int nc2 = min(BM_CAND, total - nb);
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int r0 = (i * 4 + wid) * 4;                      // this wave instruction's first record
-            const int r = r0 + rl;
-            if (rl < 4 && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rp, &recs2[buf][r0]);
+        if (rpart < REC_CHUNKS) {
+            if (rslot < nc2) pre_rec0 = grecs[(int64_t)ids[rslot] * FACE_REC_U4 + rpart];
+            if (16 + rslot < nc2) pre_rec1 = grecs[(int64_t)ids[16 + rslot] * FACE_REC_U4 + rpart];
         }
-        if (wid == 1 && (lane >> 1) < nc2)                         // lane: masks of (face lane / 2, waves 2 (lane & 1), + 1)
-            glds16(hit_masks + walk_entry(nb + (lane >> 1)) * 4 + (lane & 1) * 2, &s_hit2[buf][0]);
+        if (tid < BM_SLOTS && (tid >> 2) < nc2) pre_hit = hit_masks[walk_entry(nb + (tid >> 2)) * 4 + (tid & 3)];
     };
-    if (total > 0) {                                               // first chunk: synchronously
-        request_ids(0, 0);
+    // store what request_chunk + the id window load brought in into buffer `buf`
+    auto store_chunk = [&](int buf, int nb) {
+        const int nc2 = min(BM_CAND, total - nb);
+        if (rpart < REC_CHUNKS) {
+            if (rslot < nc2) reinterpret_cast<uint4*>(&recs2[buf][rslot])[rpart] = pre_rec0;
+            if (16 + rslot < nc2) reinterpret_cast<uint4*>(&recs2[buf][16 + rslot])[rpart] = pre_rec1;
+        }
+        if (tid < BM_SLOTS && (tid >> 2) < nc2) s_hit2[buf][tid] = pre_hit;
+        if (tid < 2 * BM_CAND) s_ids2[buf][tid] = pre_id;
+    };
+    if (total > 0) {                                               // first chunk: the id window synchronously, then its request
+        if (tid < 2 * BM_CAND) { pre_id = (tid < total) ? face_list[walk_entry(tid)] : 0u; s_ids2[0][tid] = pre_id; }
         __syncthreads();
-        request_chunk(0, 0, s_ids2[0]);
+        request_chunk(0, s_ids2[0]);
+        store_chunk(0, 0);
     }
 
     STAMP(0)
@@ -207,11 +198,10 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             n = lo;
         }
         const int S = s_base[4 * n];
-        // ---- the next chunk starts at base + n: request it now.  hipcc drains the LDS-direct loads at the next
-        // __syncthreads() (behind phase B2, the longest phase), after which the other buffers hold the next chunk.
+        // ---- the next chunk starts at base + n: request it now, it lands during B2 .. flush --------------------
         if (base + n < total) {
-            request_chunk(cur ^ 1, base + n, s_ids + n);
-            request_ids(cur ^ 1, base + n);
+            request_chunk(base + n, s_ids + n);
+            if (tid < 2 * BM_CAND) pre_id = (base + n + tid < total) ? face_list[walk_entry(base + n + tid)] : 0u;
         }
         STAMP(4)
 
@@ -233,13 +223,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const FaceRec& fc = recs[j];
             const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pxmax = pxmin + 1;
             const float pymin = (float)(uint32_t)(Y0a + (q >> 4)), pymax = pymin + 1;
-            // The forward blended this pair: its clip (aa.h:446-504) returned no error and a positive area, the ray met the
-            // face's plane and the coverage was not 0.  Those decisions are NOT taken again here (the segment formulation
-            // may round an area of 1e-9 to 0, or 1 to 1 - 1 ulp): a pair of the masks is replayed whatever the values say,
-            // otherwise the per-pixel replay below would lose its place in the list.
+            // the forward blended this pair: its clip (aa.h:446-504) returned no error and a positive area
             float oarea;
             seg_area_grad(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, dg);
-            oarea = fmaxf(oarea, 0.0f);
             BmPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
             ratio = oarea / pix_area;
             const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
@@ -251,15 +237,17 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
                 i0 = 1 - iuc - ivc; i1 = iuc; i2 = ivc;
                 ratio = mix_coverage(code, ratio, temp);
-                float c0 = i0 * fc.col[0] + i1 * fc.col[3] + i2 * fc.col[6];
-                float c1 = i0 * fc.col[1] + i1 * fc.col[4] + i2 * fc.col[7];
-                float c2 = i0 * fc.col[2] + i1 * fc.col[5] + i2 * fc.col[8];
-                out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
-                out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
-                alpha = fc.opacity * ratio;
-                out.alpha = alpha;
-                out.flags = MB_BLEND;
-                blend = true;
+                if (ratio != 0.0f) {
+                    float c0 = i0 * fc.col[0] + i1 * fc.col[3] + i2 * fc.col[6];
+                    float c1 = i0 * fc.col[1] + i1 * fc.col[4] + i2 * fc.col[7];
+                    float c2 = i0 * fc.col[2] + i1 * fc.col[5] + i2 * fc.col[8];
+                    out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
+                    out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
+                    alpha = fc.opacity * ratio;
+                    out.alpha = alpha;
+                    out.flags = MB_BLEND;
+                    blend = true;
+                }
             }
             s_pair[tid] = out;
             if (blend) atomicOr(&s_mask[q], 1ull << j);
@@ -281,9 +269,6 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 const int t = jj * 4 + wid;
                 BmPair& pr = s_pair[s_base[t] + __popcll(s_hit[t] & ((1ull << lane) - 1ull))];
                 const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
-                // alpha == 1 exactly (backward.cu:396) is the forward's decision too: only a pixel's LAST contributor can
-                // have it (T drops to 0 and the pixel is done), and then final_T is exactly 0
-                const bool alpha_is_one = (a == 1.0f) || (T_first_pass && T_final == 0.0f);
                 if (!T_first_pass) T = T / (1.f - a);                             // backward.cu:340-348
                 T_first_pass = false;
                 float dL_dalpha = 0.0f;
@@ -300,7 +285,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 float bg_dot = 0.f;
                 bg_dot += bg0 * dLc0; bg_dot += bg1 * dLc1; bg_dot += bg2 * dLc2;
                 const float bd_dot = (float)(0.0 + 1.0 * (double)dLd);            // backward.cu:394
-                if (alpha_is_one) {
+                if (a == 1.0f) {
                     dL_dalpha += (-prev_T_final) * bg_dot;
                     dL_dalpha += (-prev_T_final) * bd_dot;
                 } else {
@@ -314,6 +299,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
         STAMP(7)
         __syncthreads();
+        if (base + n < total) store_chunk(cur ^ 1, base + n);       // the next chunk's inputs have had B2 + C to arrive
         STAMP(8)
 
         // ---- phase D: chain rule + per-entry accumulation ----------------------------------------

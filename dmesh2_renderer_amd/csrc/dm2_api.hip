@@ -133,7 +133,7 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
     if (count < 0) count = 0;
     if (aux < 0) aux = 0;
     switch (kind) {
-        case DM2_SCRATCH_FACE: dm2::FaceState::carve(nullptr, count, dm2::scan_temp_bytes(count), &total); break;
+        case DM2_SCRATCH_FACE: dm2::FaceState::carve(nullptr, count, dm2::scan_temp_bytes(count), aux != 0, &total); break;
         case DM2_SCRATCH_IMAGE: dm2::ImageState::carve(nullptr, count, aux, &total); break;
         case DM2_SCRATCH_BINNING: dm2::BinningState::carve(nullptr, count, dm2::sort_temp_bytes(count, aux), &total); break;
         case DM2_SCRATCH_LAYER_IMAGE: dm2::LayerImageState::carve(nullptr, count, aux, &total); break;
@@ -149,9 +149,9 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
     const int64_t BF = (int64_t)d->B * d->F;
     *num_rendered = 0;
     if (d->P == 0 || BF == 0) return 0;                                  // render.cu:149
-    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
-    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
-    dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, st);
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), true);
+    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d, st));
     DM2_HIP(hipGetLastError());
     return read_last_offset(fs.face_offsets, BF, st, num_rendered);
 }
@@ -168,11 +168,12 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_s
     const bool have_faces = (d->P != 0 && BF != 0);
     dm2::BinningState bs{};
     if (have_faces) {
-        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
         if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
-        dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+        dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), true);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
-        dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.depths, fs, bs, is.ranges, st);   // renderer.cu:192
+        is.face_recs = fs.recs;
+        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.depths, fs, bs, is.ranges, st));   // renderer.cu:192
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
@@ -182,18 +183,22 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_s
 }
 
 int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL_dout_color, const float* dL_dout_depth,
-                 const void* binning_scratch, size_t binning_bytes, const void* image_scratch, size_t image_bytes,
+                 const void* face_scratch, size_t face_bytes, const void* binning_scratch, size_t binning_bytes,
+                 const void* image_scratch, size_t image_bytes,
                  float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity, float* dL_dverts_ndc,
                  float* dL_dfaces_intense, float* dL_daa_face_verts, void* stream) {
     if (check_render_desc(d)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
     if (d->F == 0 || d->P == 0 || N == 0 || num_rendered <= 0) return 0;       // render.cu:320
+    const int64_t BF = (int64_t)d->B * d->F;
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
     dm2::ImageState is = dm2::ImageState::carve(const_cast<void*>(image_scratch), N, Tn);
     dm2::BinningState bs = dm2::BinningState::carve(const_cast<void*>(binning_scratch), num_rendered,
                                                     dm2::sort_temp_bytes(num_rendered, Tn));
+    is.face_recs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, dm2::scan_temp_bytes(BF), true).recs;
     dm2::launch_render_backward(*d, is.ranges, bs.face_list, is, dL_dout_color, dL_dout_depth, dL_dverts, dL_dverts_color,
                                 dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs.hit_masks, bs.hit_valid, st);
     DM2_HIP(hipGetLastError());
@@ -218,9 +223,9 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     *num_rendered = 0;
     if (BF == 0) return 0;
     if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
-    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), false);
     // patch_min = 0 (renderer.cu:557-558): a null patch_min means "all zeros"
-    dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, st);
+    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr, st));
     DM2_HIP(hipGetLastError());
     return read_last_offset(fs.face_offsets, BF, st, num_rendered);
 }
@@ -239,9 +244,9 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, void* face_sc
     if (BF != 0) {
         if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
         if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
-        fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF));
+        fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), false);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
-        dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.min_depths, fs, bs, ls.ranges, st);   // renderer.cu:603
+        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.min_depths, fs, bs, ls.ranges, st));   // renderer.cu:603
     } else {
         DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
@@ -279,10 +284,24 @@ int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc,
     return 0;
 }
 
+int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, const float* aa_face_edges,
+                         const uint8_t* aa_face_edges_iszero, const float* aa_face_edges_recip, const float* aa_face_edges_normal,
+                         const float* aa_face_edges_normal_c, const float* pixmin, float* area, float* grad, int32_t* code,
+                         void* stream) {
+    if (variant < 0 || variant > 2) return fail("dm2_debug_aa_overlap: unknown variant");
+    if (n < 0) return fail("dm2_debug_aa_overlap: negative count");
+    if (n > 0 && (!aa_face_verts || !aa_face_edges || !aa_face_edges_iszero || !aa_face_edges_recip || !aa_face_edges_normal ||
+                  !aa_face_edges_normal_c || !pixmin || !area || !grad || !code))
+        return fail("dm2_debug_aa_overlap: null pointer");
+    dm2::launch_debug_aa_overlap(variant, n, aa_face_verts, aa_face_edges, aa_face_edges_iszero, aa_face_edges_recip,
+                                 aa_face_edges_normal, aa_face_edges_normal_c, pixmin, area, grad, code, (hipStream_t)stream);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
 int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, const void* scratch, size_t scratch_bytes,
                     void* dst, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    (void)scratch_bytes;
     void* base = const_cast<void*>(scratch);
     const void* src = nullptr; size_t bytes = 0;
     switch (what) {
@@ -296,6 +315,8 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, 
         case 7: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.ranges; bytes = (size_t)aux * 8; break; }
         default: return fail("dm2_debug_fetch: unknown item");
     }
+    if (!scratch && bytes) return fail("dm2_debug_fetch: null scratch");
+    if (bytes && (size_t)((const char*)src - (const char*)scratch) + bytes > scratch_bytes) return fail("dm2_debug_fetch: item lies beyond scratch_bytes");
     if (bytes) DM2_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }

@@ -40,7 +40,10 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
                   ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                   float* __restrict__ dL_dverts, float* __restrict__ dL_dverts_color,
                   float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
-                  float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts) {
+                  float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts,
+                  const uint32_t* __restrict__ skip_if_masks) {
+    // launched behind k_render_backward_mask as its fallback: that kernel did the work when the forward left masks
+    if (skip_if_masks && skip_if_masks[0] == 2u) return;
     __shared__ FaceRec recs[BWD_CHUNK];
     __shared__ float acc[BWD_CHUNK * ACC_STRIDE];
     __shared__ uint32_t s_max_lc;
@@ -94,7 +97,7 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
         __syncthreads();                                            // previous chunk flushed
         const int n = min(BWD_CHUNK, total - base);
         // recs[j] = entry (total-1) - (base+j): back to front (backward.cu:171)
-        if (tid < n) stage_face(d, b, (int)face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
+        if (tid < n) stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
         for (int k = tid; k < n * ACC_STRIDE; k += TILE_PIX) acc[k] = 0.f;
         __syncthreads();
 
@@ -237,29 +240,24 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
             return;
         }
 #endif
-        if (d.aa_temperature > 0.0f) {
+        if (d.aa_temperature > 0.0f && hit_masks && hit_valid) {
             // Two launches, one of which returns at once (decided on the device by hit_valid, no host read-back): when this
-            // frame's forward left its blend masks, dm2_backward_mask.hip uses them; otherwise dm2_backward_queue.hip
-            // enumerates and classifies the pairs itself.  -DDM2_BWD_NO_MASKS: always the latter (A/B).
+            // frame's forward left its blend masks (dm2_forward_queue.hip), dm2_backward_mask.hip uses them; otherwise (the
+            // forward ran with DM2_FLAG_LEGACY_KERNELS) the per-pixel walk below does the work.
             StageTimer tm(ST_BWD, st);
-#ifndef DM2_BWD_NO_MASKS
-            if (hit_masks && hit_valid) {
-                launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                            dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
-                launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                             dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid, st);
-                return;
-            }
-#endif
-            launch_render_backward_queue(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, nullptr, st);
+            launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                        dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
+            const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+            hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+                               dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid);
             return;
         }
     }
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts);
+                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
+                       (const uint32_t*)nullptr);
 }
 
 }  // namespace dm2

@@ -119,7 +119,7 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
         __syncthreads();                                            // previous chunk flushed, LDS reusable
         const int n = min(BP_CHUNK, total - base);
         // recs[j] = entry (total-1) - (base+j): back to front (backward.cu:171)
-        if (tid < n) stage_face(d, b, (int)face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
+        if (tid < n) stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + (uint32_t)(total - 1 - base - tid)], recs[tid]);
         for (int k = tid; k < n * BP_ACC; k += TILE_PIX) acc[k] = 0.f;
         __syncthreads();
 

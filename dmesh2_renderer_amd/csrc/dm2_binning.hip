@@ -12,14 +12,18 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dm2_device_math.h"
+#include "dm2_stage.h"
 #include "dm2_state.h"
 
 namespace dm2 {
 
+// PACK: also write the face's packed record (dm2_stage.h) for the composite kernels -- only for faces that reach a
+// tile list.  `d` is read only then.
+template <bool PACK>
 __global__ void __launch_bounds__(256)
 k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __restrict__ patch_min,
              const int32_t* __restrict__ faces, const float* __restrict__ verts_ndc,
-             const float* __restrict__ verts_image, FaceState fs) {
+             const float* __restrict__ verts_image, FaceState fs, dm2_render_desc d) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * F) return;
     const int b = (int)(idx / F), f = (int)(idx % F);
@@ -51,6 +55,15 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     fs.tiles_touched[idx] = touched;
     fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
     fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
+    if (PACK && touched != 0) {
+        FaceRec r;
+        pack_face(d, b, f, r);
+        r.pad[0] = 0.f;
+        const uint4* src = reinterpret_cast<const uint4*>(&r);
+        uint4* dst = fs.recs + idx * FACE_REC_U4;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -113,24 +126,29 @@ size_t sort_temp_bytes(int64_t R, int64_t Tn) {
     return bytes;
 }
 
-void launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
-                            const float* verts_ndc, const float* verts_image, FaceState fs, hipStream_t st) {
+hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
+                                  const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
+                                  hipStream_t st) {
     const int64_t BF = (int64_t)B * F;
-    if (BF == 0) return;
+    if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
-    hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs);
+    if (pack && fs.recs)
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
+                           dm2_render_desc{});
     size_t bytes = fs.scan_temp_bytes;
-    (void)rocprim::inclusive_scan(fs.scan_temp, bytes, fs.tiles_touched, fs.face_offsets, (size_t)BF, rocprim::plus<uint32_t>(), st);
+    return rocprim::inclusive_scan(fs.scan_temp, bytes, fs.tiles_touched, fs.face_offsets, (size_t)BF, rocprim::plus<uint32_t>(), st);
 }
 
-void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
-                     uint2* ranges, hipStream_t st) {
+hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
+                           uint2* ranges, hipStream_t st) {
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
-    (void)hipMemsetAsync(ranges, 0, (size_t)Tn * sizeof(uint2), st);           // renderer.cu:211
-    if (R <= 0) return;
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)Tn * sizeof(uint2), st);           // renderer.cu:211
+    if (e != hipSuccess || R <= 0) return e;
     const int64_t BF = (int64_t)B * F;
     {
         StageTimer tm(ST_EMIT, st);
@@ -140,11 +158,13 @@ void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_dep
     {
         StageTimer tm(ST_SORT, st);
         size_t bytes = bs.sort_temp_bytes;
-        (void)rocprim::radix_sort_pairs(bs.sort_temp, bytes, bs.keys_unsorted, bs.keys, bs.face_list_unsorted, bs.face_list,
-                                        (size_t)R, 0u, sort_end_bit(Tn), st);
+        e = rocprim::radix_sort_pairs(bs.sort_temp, bytes, bs.keys_unsorted, bs.keys, bs.face_list_unsorted, bs.face_list,
+                                      (size_t)R, 0u, sort_end_bit(Tn), st);
+        if (e != hipSuccess) return e;
     }
     StageTimer tm(ST_RANGES, st);
     hipLaunchKernelGGL(k_tile_ranges, dim3((int)((R + 255) / 256)), dim3(256), 0, st, R, bs.keys, ranges, bs.hit_valid);
+    return hipSuccess;
 }
 
 }  // namespace dm2

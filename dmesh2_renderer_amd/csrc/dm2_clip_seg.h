@@ -3,56 +3,56 @@
 //
 // The reference builds the clipped polygon in a vertex table, fan-triangulates it and differentiates every
 // fan triangle through the Jacobians of its three corners (aa.h:151-441).  The backward kernels only meet
-// pairs whose forward clip returned "no error, area > 0" (the forward's blend masks say so), which makes a
-// much shorter formulation possible -- no table, no walk, no corner codes:
+// pairs whose forward clip returned "no error, area > 0" (the forward's blend masks say so).  This file
+// rebuilds exactly the reference's polygon -- the same corners in the same cyclic order, also where exact
+// ties make that polygon geometrically inconsistent (with fp32 image coordinates a triangle corner lies
+// EXACTLY on a pixel boundary about once in 10^4, and the reference then returns whatever its rules give) --
+// but without a table, a walk loop or corner codes:
 //
-//   * Per triangle edge the part inside the pixel is ONE segment [start, end]; start / end is either the
-//     edge's end point (inside the pixel) or its crossing with a pixel edge.  The crossings, their validity
-//     tests and the sort by t are the reference's expressions (aa.h:230-258, :308-313), evaluated on the
-//     same operands as in the forward: the decisions are bit-for-bit the forward's, so the error paths
-//     E00-E03 cannot occur here.
-//   * Gradient.  Summed over the fan, the reference's per-triangle partials telescope to the shoelace form
-//     dA/dc = 1/2 (y_next - y_prev, x_prev - x_next) per polygon corner c.  Pixel corners have a zero
-//     Jacobian.  A crossing on a y = const pixel edge moves only in x, and its neighbour on the pixel
-//     boundary has the same y, so its shoelace weight is 1/2 (end.y - start.y) of ITS OWN segment; likewise
-//     1/2 (start.x - end.x) for a crossing on an x = const edge.  A triangle corner inside the pixel joins two
-//     segments: weight 1/2 (end_next.y - start_prev.y, start_prev.x - end_next.x), Jacobian identity.  The
-//     crossing Jacobians are aa.h:276-294 (t, gt0, gt1 as written there).  The entries the reference
-//     multiplies with the weight's other component are (1 - t) + gt0*e and t + gt1*e, zero up to rounding
-//     (the crossing does not leave its pixel edge); they are not issued.  Same polynomial as the reference's
-//     in the same corner coordinates, regrouped: agrees with the oracle to ~4e-7 absolute (tests).
-//   * Area.  Shoelace in pixel-local coordinates (the subtraction of the pixel origin is exact): 1/2 cross per
-//     segment plus the pixel-boundary pieces between an exit crossing and the next entry crossing, which are
-//     a function G of the perimeter coordinate.  Agrees with the reference's fan sum to 1 ulp of the pixel
-//     area (6e-8); the backward only needs alpha to that accuracy (the blend decision is the forward's).
+//   * Per triangle edge the reference emits at most two corners with a non-zero Jacobian: [entry crossing,
+//     exit crossing], [entry crossing, end point p1], [exit crossing] or [p1] (aa.h:304-357), decided by its
+//     crossing-validity and point-in-pixel tests (aa.h:230-258, :308-313).  Those tests are evaluated here by
+//     the same expressions on the same operands as in the forward, so the decisions are the forward's bit for
+//     bit and the error paths E00-E03 cannot occur.
+//   * Behind an exit crossing on pixel edge e the reference appends the pixel corners e+1, e+2, ... while they
+//     are inside all three half planes (aa.h:359-379, the classification of aa.h:103-149): a count of
+//     consecutive set bits of the 4-bit corner mask, no loop.
+//   * So every emitted corner knows its polygon neighbours in closed form: within the edge, the first / last
+//     walked pixel corner, or the first corner of the next edge that emits anything (the last one of the
+//     previous edge).  Gradient: summed over the fan, the reference's per-triangle partials (aa.h:415-433)
+//     telescope to the shoelace form dA/dc = 1/2 (y_next - y_prev, x_prev - x_next) per corner, pushed through
+//     the corner's Jacobian (identity for p1, aa.h:276-294 for a crossing, zero for a pixel corner).  Same
+//     polynomial in the same corner coordinates, regrouped: agrees with the oracle to ~1e-6 absolute.
+//   * Area: shoelace over the same cyclic sequence in pixel-local coordinates (the subtraction of the pixel
+//     origin is exact); the pixel-corner chain contributes 1/2 per traversed x = xmax or y = ymax edge.
+//     Agrees with the reference's fan sum to 2 ulp of the pixel area; the backward only needs alpha to that
+//     accuracy (the blend decision itself is the forward's, never re-taken).
 //
-// tests/test_gpu_clippers.py runs this function on the reference-produced vectors (tests/golden/aa_pairs.npz)
-// through dm2_debug_aa_overlap.
+// tests/test_gpu_clippers.py runs this function on the reference-produced vectors (tests/golden/aa_pairs.npz,
+// aa_error_pairs.npz), on random pairs and on exact-tie stress sets through dm2_debug_aa_overlap.
 #pragma once
+#include <type_traits>
+
+#include "dm2_clip_area.h"
 #include "dm2_device_math.h"
 
 namespace dm2 {
 
 struct EdgeSeg {
-    bool has;           // the edge has a piece inside the pixel
-    bool sX, eX;        // start / end is a crossing (otherwise the edge's own end point p_i / p_{i+1})
-    float sx, sy, ex, ey;
-    float ps, pe;       // perimeter coordinate of start / end (meaningful for crossings only)
+    bool has;           // the edge emits at least one corner
+    bool sX, eX;        // first emitted corner is an (entry) crossing / last emitted non-pixel corner is an (exit) crossing
+    float sx, sy;       // the entry crossing (meaningful when sX)
+    float ex, ey;       // the last emitted non-pixel corner: exit crossing (eX) or the edge's end point p1
+    float st, et;       // crossing parameters
+    int spe, epe;       // pixel edges of the crossings (0: y = ymin, 1: x = xmax, 2: y = ymax, 3: x = xmin)
+    int k;              // pixel corners appended behind the exit crossing
+    float ax, ay;       // first emitted corner
+    float lx, ly;       // last emitted corner (a pixel corner when k > 0)
+    float wx, wy;       // first appended pixel corner (meaningful when k > 0)
 };
 
-// perimeter coordinate of a point on pixel edge `pedge` (0: y = ymin, 1: x = xmax, 2: y = ymax, 3: x = xmin), CCW
-// from corner (xmin, ymin); lx, ly are pixel-local
-__device__ __forceinline__ float perimeter_coord(int pedge, float lx, float ly) {
-    const float along = (pedge & 1) ? ly : lx;
-    const float fwd = (pedge & 2) ? 1.0f - along : along;
-    return (float)pedge + fwd;
-}
-// shoelace weight of the pixel boundary from perimeter coordinate 0 to s (local origin at (xmin, ymin)): only the
-// x = xmax and y = ymax edges contribute
-__device__ __forceinline__ float perimeter_area(float s) { return 0.5f * fminf(fmaxf(s - 1.0f, 0.0f), 2.0f); }
-
 template <int TI>
-__device__ __forceinline__ void seg_edge(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax, EdgeSeg& S, float* g) {
+__device__ __forceinline__ void seg_edge(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax, uint32_t inside, EdgeSeg& S) {
     constexpr int TJ = (TI + 1) % 3;
     const float p0x = f.v[2 * TI], p0y = f.v[2 * TI + 1], p1x = f.v[2 * TJ], p1y = f.v[2 * TJ + 1];
     const float ex = f.e[2 * TI], ey = f.e[2 * TI + 1], rx = f.r[2 * TI], ry = f.r[2 * TI + 1];
@@ -79,37 +79,54 @@ __device__ __forceinline__ void seg_edge(const AAFace& f, float pxmin, float pxm
     const int pe1 = vD ? 3 : (vC ? 2 : (vB ? 1 : 0));
     const bool two = pe0 != pe1;                                       // (with `any`) two valid crossings: the forward excluded > 2
     const bool sw = t0 > t1;                                           // aa.h:308-313 (equal when there is one crossing)
-    // [start, end]: entry crossing (or p0 when it is inside), exit crossing (or p1)
+    // emitted: two crossings [a, b]; one crossing and p0 outside [c, p1]; one crossing and p0 inside [c]; none, both inside [p1]
     const bool sX = any && (two || !p0in), eX = any && (two || p0in);
     S.has = any || p0in;                                               // no crossing: both end points inside, or the edge misses the pixel
     S.sX = sX; S.eX = eX;
-    const float cs_x = sw ? x1 : x0, cs_y = sw ? y1 : y0, cs_t = sw ? t1 : t0;
-    const float ce_x = sw ? x0 : x1, ce_y = sw ? y0 : y1, ce_t = sw ? t0 : t1;
-    const int cs_pe = sw ? pe1 : pe0, ce_pe = sw ? pe0 : pe1;
-    S.sx = sX ? cs_x : p0x; S.sy = sX ? cs_y : p0y;
-    S.ex = eX ? ce_x : p1x; S.ey = eX ? ce_y : p1y;
-    S.ps = perimeter_coord(cs_pe, S.sx - pxmin, S.sy - pymin);
-    S.pe = perimeter_coord(ce_pe, S.ex - pxmin, S.ey - pymin);
-    // shoelace weights of a crossing of this segment on a y = const / x = const pixel edge
-    const float wH = 0.5f * (S.ey - S.sy), wV = 0.5f * (S.sx - S.ex);
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;                      // d/d(p0x, p0y), d/d(p1x, p1y)
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const bool on = k == 0 ? sX : eX;
-        const int pe = k == 0 ? cs_pe : ce_pe;
-        const float t = k == 0 ? cs_t : ce_t;
-        const bool isH = (pe & 1) == 0;
-        const float w = isH ? ((pe & 2) ? pymax : pymin) : ((pe & 2) ? pxmin : pxmax);     // the pixel edge's constant
-        const float p0a = isH ? p0y : p0x, p1a = isH ? p1y : p1x, ra = isH ? ry : rx, eo = isH ? ex : ey;
-        const float wt = isH ? wH : wV;
-        const float gt0 = (w - p1a) * ra * ra, gt1 = (-w + p0a) * ra * ra;                // aa.h:276-279
-        const float omt = (float)(1.0 - (double)t);
-        const float u0 = omt * wt, u1 = (gt0 * eo) * wt, v0 = t * wt, v1 = (gt1 * eo) * wt;
-        // H: the crossing moves in x: d(x)/d(p0) = (omt, gt0*ex), d(x)/d(p1) = (t, gt1*ex);  V: in y, components swapped
-        a0 += on ? (isH ? u0 : u1) : 0.f; a1 += on ? (isH ? u1 : u0) : 0.f;
-        b0 += on ? (isH ? v0 : v1) : 0.f; b1 += on ? (isH ? v1 : v0) : 0.f;
-    }
-    g[2 * TI] += a0; g[2 * TI + 1] += a1; g[2 * TJ] += b0; g[2 * TJ + 1] += b1;
+    S.sx = sw ? x1 : x0; S.sy = sw ? y1 : y0; S.st = sw ? t1 : t0; S.spe = sw ? pe1 : pe0;
+    const float cx = sw ? x0 : x1, cy = sw ? y0 : y1;
+    S.et = sw ? t0 : t1; S.epe = sw ? pe0 : pe1;
+    S.ex = eX ? cx : p1x; S.ey = eX ? cy : p1y;
+    S.ax = sX ? S.sx : S.ex; S.ay = sX ? S.sy : S.ey;
+    // pixel corners behind the exit crossing: corner (epe + 1) & 3, ... while inside (the caller excluded inside == 0xF)
+    const int c1 = (S.epe + 1) & 3;
+    const uint32_t rot = ((inside | (inside << 4)) >> c1) & 0xFu;
+    const int k = (rot & 1u) ? ((rot & 2u) ? ((rot & 4u) ? 3 : 2) : 1) : 0;
+    S.k = (S.has && eX) ? k : 0;
+    const int lc = (S.epe + S.k) & 3;
+    S.wx = (c1 == 1 || c1 == 2) ? pxmax : pxmin; S.wy = (c1 & 2) ? pymax : pymin;
+    const float lcx = (lc == 1 || lc == 2) ? pxmax : pxmin, lcy = (lc & 2) ? pymax : pymin;
+    S.lx = S.k > 0 ? lcx : S.ex; S.ly = S.k > 0 ? lcy : S.ey;
+}
+
+// d(area) of one crossing of edge TI with shoelace weight (gax, gay): aa.h:276-294 (t, gt0, gt1 as written there)
+template <int TI>
+__device__ __forceinline__ void seg_push_crossing(const AAFace& f, bool on, int pe, float t, float pxmin, float pxmax, float pymin,
+                                                  float pymax, float gax, float gay, float* g) {
+    constexpr int TJ = (TI + 1) % 3;
+    const float p0x = f.v[2 * TI], p0y = f.v[2 * TI + 1], p1x = f.v[2 * TJ], p1y = f.v[2 * TJ + 1];
+    const float ex = f.e[2 * TI], ey = f.e[2 * TI + 1], rx = f.r[2 * TI], ry = f.r[2 * TI + 1];
+    const bool isH = (pe & 1) == 0;                                    // crossing of a y = const pixel edge: x was computed
+    const float w = isH ? ((pe & 2) ? pymax : pymin) : ((pe & 2) ? pxmin : pxmax);       // the pixel edge's constant
+    const float p0a = isH ? p0y : p0x, p1a = isH ? p1y : p1x, ra = isH ? ry : rx;
+    const float ea = isH ? ey : ex, eo = isH ? ex : ey;               // edge component along the crossing axis / the other one
+    const float gm = isH ? gax : gay, gr = isH ? gay : gax;           // weight of the computed coordinate / of the fixed one
+    const float gt0 = (w - p1a) * ra * ra, gt1 = (-w + p0a) * ra * ra;
+    const float omt = 1.0f - t;                                        // == (float)(1.0 - (double)t)
+    // computed coordinate m = p0o + t * eo: dm/dp0 = (omt [other axis], gt0 * eo [crossing axis]), dm/dp1 = (t, gt1 * eo);
+    // fixed coordinate:  d/dp0 = ((1 - t) + gt0 * ea) on the crossing axis (zero up to rounding), d/dp1 = (t + gt1 * ea)
+    const float a_o = omt * gm, a_a = (gt0 * eo) * gm + (omt + gt0 * ea) * gr;
+    const float b_o = t * gm, b_a = (gt1 * eo) * gm + (t + gt1 * ea) * gr;
+    // H: other axis = x, crossing axis = y
+    g[2 * TI] += on ? (isH ? a_o : a_a) : 0.f; g[2 * TI + 1] += on ? (isH ? a_a : a_o) : 0.f;
+    g[2 * TJ] += on ? (isH ? b_o : b_a) : 0.f; g[2 * TJ + 1] += on ? (isH ? b_a : b_o) : 0.f;
+}
+
+// 1/2 * (shoelace terms of the pixel-corner chain c1 -> c1+1 -> ... -> c1+k-1): only the transitions along x = xmax
+// (corner 1 -> 2) and y = ymax (2 -> 3) have a non-zero cross product in pixel-local coordinates
+__device__ __forceinline__ float corner_chain_area(int c1, int k) {
+    auto G = [](float u) { return 0.5f * (fminf(fmaxf(u - 1.0f, 0.0f), 2.0f) + fminf(fmaxf(u - 5.0f, 0.0f), 2.0f)); };
+    return k > 0 ? G((float)(c1 + k - 1)) - G((float)c1) : 0.0f;
 }
 
 // Area and d(area)/d(corners) of pixel [pxmin,pxmax]x[pymin,pymax] and face f, for a pair whose reference clip
@@ -118,34 +135,49 @@ __device__ __forceinline__ void seg_area_grad(const AAFace& f, float pxmin, floa
                                               float pix_area, float& area, float* g) {
 #pragma unroll
     for (int k = 0; k < 6; k++) g[k] = 0.f;
+    uint32_t inside;
+    classify_pixel(f, pxmin, pxmax, pymin, pymax, inside);            // aa.h:103-149 (the forward passed its all-outside test)
+    if (inside == 0xFu) { area = pix_area; return; }                  // aa.h:493-496: not clipped at all, zero Jacobian
     EdgeSeg S0, S1, S2;
-    seg_edge<0>(f, pxmin, pxmax, pymin, pymax, S0, g);
-    seg_edge<1>(f, pxmin, pxmax, pymin, pymax, S1, g);
-    seg_edge<2>(f, pxmin, pxmax, pymin, pymax, S2, g);
-    // triangle corners inside the pixel: p1 joins segments 0 and 1, p2 joins 1 and 2, p0 joins 2 and 0
-    {
-        const bool in1 = S0.has && !S0.eX, in2 = S1.has && !S1.eX, in0 = S2.has && !S2.eX;
-        g[2] += in1 ? 0.5f * (S1.ey - S0.sy) : 0.f; g[3] += in1 ? 0.5f * (S0.sx - S1.ex) : 0.f;
-        g[4] += in2 ? 0.5f * (S2.ey - S1.sy) : 0.f; g[5] += in2 ? 0.5f * (S1.sx - S2.ex) : 0.f;
-        g[0] += in0 ? 0.5f * (S0.ey - S2.sy) : 0.f; g[1] += in0 ? 0.5f * (S2.sx - S0.ex) : 0.f;
-    }
-    if (!(S0.has || S1.has || S2.has)) { area = pix_area; return; }   // no edge reaches the pixel: it lies inside (aa.h:493-496)
-    // shoelace: segments in pixel-local coordinates + the pixel boundary from every exit crossing to the next entry crossing
-    float a = 0.f;
-    const float gs0 = perimeter_area(S0.ps), gs1 = perimeter_area(S1.ps), gs2 = perimeter_area(S2.ps);
-    auto piece = [&](const EdgeSeg& S, const EdgeSeg& N1, float gN1, const EdgeSeg& N2, float gN2, float gSelf) {
-        const float ax = S.sx - pxmin, ay = S.sy - pymin, bx = S.ex - pxmin, by = S.ey - pymin;
-        const float seg = 0.5f * (ax * by - bx * ay);
-        const float nps = N1.has ? N1.ps : (N2.has ? N2.ps : S.ps);
-        const float ngs = N1.has ? gN1 : (N2.has ? gN2 : gSelf);
-        float walk = ngs - perimeter_area(S.pe);
-        walk += (nps < S.pe) ? 1.0f : 0.0f;                            // wrapped past corner (xmin, ymin)
-        a += S.has ? seg + (S.eX ? walk : 0.f) : 0.f;
+    seg_edge<0>(f, pxmin, pxmax, pymin, pymax, inside, S0);
+    seg_edge<1>(f, pxmin, pxmax, pymin, pymax, inside, S1);
+    seg_edge<2>(f, pxmin, pxmax, pymin, pymax, inside, S2);
+    // previous / next edge that emits anything (itself when it is the only one)
+    auto sel = [](bool c1, float a, bool c2, float b, float self) { return c1 ? a : (c2 ? b : self); };
+    // last corner before edge i's first, first corner behind edge i's last
+    const float P0x = sel(S2.has, S2.lx, S1.has, S1.lx, S0.lx), P0y = sel(S2.has, S2.ly, S1.has, S1.ly, S0.ly);
+    const float P1x = sel(S0.has, S0.lx, S2.has, S2.lx, S1.lx), P1y = sel(S0.has, S0.ly, S2.has, S2.ly, S1.ly);
+    const float P2x = sel(S1.has, S1.lx, S0.has, S0.lx, S2.lx), P2y = sel(S1.has, S1.ly, S0.has, S0.ly, S2.ly);
+    const float N0x = sel(S1.has, S1.ax, S2.has, S2.ax, S0.ax), N0y = sel(S1.has, S1.ay, S2.has, S2.ay, S0.ay);
+    const float N1x = sel(S2.has, S2.ax, S0.has, S0.ax, S1.ax), N1y = sel(S2.has, S2.ay, S0.has, S0.ay, S1.ay);
+    const float N2x = sel(S0.has, S0.ax, S1.has, S1.ax, S2.ax), N2y = sel(S0.has, S0.ay, S1.has, S1.ay, S2.ay);
+    float a2 = 0.f;                                                   // twice the area
+    auto edge = [&](auto ti, const EdgeSeg& S, float Px, float Py, float Nx, float Ny) {
+        constexpr int TI = decltype(ti)::value;
+        constexpr int TJ = (TI + 1) % 3;
+        // first emitted corner when it is the entry crossing: neighbours = (last corner before this edge, the second corner)
+        seg_push_crossing<TI>(f, S.has && S.sX, S.spe, S.st, pxmin, pxmax, pymin, pymax, 0.5f * (S.ey - Py), 0.5f * (Px - S.ex), g);
+        // last emitted non-pixel corner: previous = the entry crossing or the last corner before this edge; next = the first
+        // appended pixel corner or the first corner of the next edge
+        const float qx = S.sX ? S.sx : Px, qy = S.sX ? S.sy : Py;
+        const float nx = S.k > 0 ? S.wx : Nx, ny = S.k > 0 ? S.wy : Ny;
+        const float gax = 0.5f * (ny - qy), gay = 0.5f * (qx - nx);
+        seg_push_crossing<TI>(f, S.has && S.eX, S.epe, S.et, pxmin, pxmax, pymin, pymax, gax, gay, g);
+        const bool vert = S.has && !S.eX;                             // the edge's end point p1: identity Jacobian
+        g[2 * TJ] += vert ? gax : 0.f; g[2 * TJ + 1] += vert ? gay : 0.f;
+        // shoelace, pixel-local: (entry, last non-pixel corner), (that, first pixel corner), the chain, (last corner, next edge's first)
+        const float slx = S.sx - pxmin, sly = S.sy - pymin, elx = S.ex - pxmin, ely = S.ey - pymin;
+        const float wlx = S.wx - pxmin, wly = S.wy - pymin, llx = S.lx - pxmin, lly = S.ly - pymin;
+        const float nlx = Nx - pxmin, nly = Ny - pymin;
+        float t2 = S.sX ? (slx * ely - elx * sly) : 0.f;
+        t2 += S.k > 0 ? (elx * wly - wlx * ely) + 2.0f * corner_chain_area((S.epe + 1) & 3, S.k) : 0.f;
+        t2 += llx * nly - nlx * lly;
+        a2 += S.has ? t2 : 0.f;
     };
-    piece(S0, S1, gs1, S2, gs2, gs0);
-    piece(S1, S2, gs2, S0, gs0, gs1);
-    piece(S2, S0, gs0, S1, gs1, gs2);
-    area = a;
+    edge(std::integral_constant<int, 0>{}, S0, P0x, P0y, N0x, N0y);
+    edge(std::integral_constant<int, 1>{}, S1, P1x, P1y, N1x, N1y);
+    edge(std::integral_constant<int, 2>{}, S2, P2x, P2y, N2x, N2y);
+    area = 0.5f * a2;
 }
 
 }  // namespace dm2

@@ -51,7 +51,7 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     for (int base = 0; base < total; base += FP_CHUNK) {
         if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260 (also guards LDS reuse)
         const int n = min(FP_CHUNK, total - base);
-        if (tid < n) stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
+        if (tid < n) stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + base + tid], recs[tid]);
         __syncthreads();
 
         for (int j = 0; j < n; j++) {

@@ -121,7 +121,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
-            stage_face(d, b, (int)face_list[range.x + base + tid], recs[tid]);
+            stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + base + tid], recs[tid]);
             uint32_t rect;
             cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
             s_rect[tid] = rect;

@@ -23,6 +23,18 @@
 
 namespace dm2 {
 
+// ---- XCD-aware block -> tile order -----------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each XCD has its own L2, and
+// neighbouring tiles share faces (1.6 tiles per face at the BASELINE workload) and pixels' rays.  A 1-D grid whose
+// block L renders tile (L % 8) * ceil(Tn / 8) + L / 8 gives every XCD one contiguous band of tiles, so a face record
+// is fetched into one L2 instead of up to eight.  (Only an ordering: correctness does not depend on where a block runs.)
+__host__ __device__ __forceinline__ uint32_t tile_grid_blocks(uint32_t Tn) { return 8u * ((Tn + 7u) / 8u); }
+__device__ __forceinline__ bool tile_of_block(uint32_t Tn, uint32_t& tile) {
+    const uint32_t per = (Tn + 7u) / 8u;
+    tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    return tile < Tn;
+}
+
 // rect packing: x0 | y0<<4 | (w-1)<<8 | (h-1)<<12 ; count==0 faces keep rect 0 and are never looked up
 __device__ __forceinline__ uint32_t pack_rect(int x0, int y0, int w, int h) {
     return (uint32_t)x0 | ((uint32_t)y0 << 4) | ((uint32_t)(w - 1) << 8) | ((uint32_t)(h - 1) << 12);

@@ -3,8 +3,9 @@
 // The reference stages 96-108 B per entry in shared memory and re-reads the AA
 // tables from global memory for every (pixel,face) (forward.cu:228-243,314-317,
 // aa.h:111-120,184-203).  Here everything a (pixel,face) evaluation needs is
-// gathered ONCE per (tile,entry) into a 240-byte LDS record; the per-pixel loop
-// then reads it with wave-uniform (broadcast) ds_reads only.
+// packed ONCE per (view,face) and forward into a 256-byte global record (by the
+// preprocess kernel, dm2_binning.hip) and copied per (tile,entry) into a 240-byte
+// LDS record; the per-pixel code reads it with ds_reads only.
 #pragma once
 #include "dm2_device_math.h"
 #include "dm2_state.h"
@@ -28,8 +29,17 @@ struct __attribute__((aligned(16))) FaceRec {
 };
 static_assert(sizeof(FaceRec) == 236 + 4 * DM2_FACEREC_PAD && sizeof(FaceRec) % 16 == 0, "FaceRec layout");
 
-// Gather entry `face_id` of view `b` into `r` (one lane per record).
-__device__ __forceinline__ void stage_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
+// Copy the packed record of (view, face) `bf` into LDS (one lane per record: 15 loads of 16 bytes from two 128-byte
+// lines; the kernels with a prefetch pipeline copy cooperatively instead, 16 lanes per record).
+__device__ __forceinline__ void stage_face(const uint4* __restrict__ recs, int64_t bf, FaceRec& r) {
+    const uint4* src = recs + bf * FACE_REC_U4;
+    uint4* dst = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
+}
+
+// Gather face `face_id` of view `b` from the op's input tensors into `r` (the preprocess kernel packs with it).
+__device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
     const int v0 = d.faces[3 * face_id], v1 = d.faces[3 * face_id + 1], v2 = d.faces[3 * face_id + 2];
     r.face_id = face_id; r.vid[0] = v0; r.vid[1] = v1; r.vid[2] = v2;
     const int vs[3] = {v0, v1, v2};

@@ -28,6 +28,12 @@ struct Carver {
     size_t used(const void* base) const { return (size_t)(p - reinterpret_cast<uintptr_t>(base)); }
 };
 
+// One packed record per (view, face): everything a (pixel,face) evaluation reads (the LDS FaceRec of dm2_stage.h,
+// 240 bytes, padded to 256).  Written once per forward by the preprocess kernel, read by every list entry of the
+// composite kernels as two full 128-byte lines (instead of ~16 separate 64-byte lines gathered through three levels
+// of indices), and again by the backward: the gradients belong to the inputs the forward saw.
+constexpr int FACE_REC_U4 = 16;            // uint4 per record (256 B)
+
 // per (batch,face): produced by the preprocess kernel
 struct FaceState {
     float* depths;            // mean NDC z mapped to [0,1]  (sort key of Renderer)
@@ -38,12 +44,14 @@ struct FaceState {
     uint32_t* rect_lo;        // x0 | y0 << 16   (half-open tile rect, reused by the key emitter)
     uint32_t* rect_hi;        // x1 | y1 << 16
     void* scan_temp; size_t scan_temp_bytes;
-    static FaceState carve(void* base, int64_t BF, size_t scan_temp_bytes, size_t* total = nullptr) {
+    uint4* recs;              // (BF, FACE_REC_U4) packed face records; nullptr when the caller needs none (layers)
+    static FaceState carve(void* base, int64_t BF, size_t scan_temp_bytes, bool with_recs, size_t* total = nullptr) {
         Carver c(base); FaceState s;
         s.depths = c.take<float>(BF); s.min_depths = c.take<float>(BF); s.max_depths = c.take<float>(BF);
         s.tiles_touched = c.take<uint32_t>(BF); s.face_offsets = c.take<uint32_t>(BF);
         s.rect_lo = c.take<uint32_t>(BF); s.rect_hi = c.take<uint32_t>(BF);
         s.scan_temp = c.take<char>(scan_temp_bytes); s.scan_temp_bytes = scan_temp_bytes;
+        s.recs = with_recs ? c.take<uint4>(BF * FACE_REC_U4) : nullptr;
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }
@@ -55,8 +63,9 @@ struct ImageState {
     float* final_prev_T;      // (N)
     uint32_t* n_contrib;      // (N)
     uint2* ranges;            // (Tn) [start,end) into face_list
+    const uint4* face_recs;   // not part of the image scratch: FaceState::recs of the same forward, set by the host API
     static ImageState carve(void* base, int64_t N, int64_t Tn, size_t* total = nullptr) {
-        Carver c(base); ImageState s;
+        Carver c(base); ImageState s; s.face_recs = nullptr;
         s.final_T = c.take<float>(N); s.final_prev_T = c.take<float>(N); s.n_contrib = c.take<uint32_t>(N);
         s.ranges = c.take<uint2>(Tn);
         if (total) *total = c.used(base) + ALIGN;
@@ -103,11 +112,13 @@ size_t sort_temp_bytes(int64_t R, int64_t Tn);
 unsigned sort_end_bit(int64_t Tn);
 
 // preprocess + inclusive scan (forward.cu:16-108, renderer.cu:165-171)
-void launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
-                            const float* verts_ndc, const float* verts_image, FaceState fs, hipStream_t st);
+// pack != nullptr: also write the packed face records fs.recs from the op's inputs
+hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
+                                  const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
+                                  hipStream_t st);
 // key emit + stable sort + tile ranges (renderer.cu:185-219); key depth = depths or min_depths
-void launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
-                     uint2* ranges, hipStream_t st);
+hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
+                           uint2* ranges, hipStream_t st);
 
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
@@ -125,10 +136,6 @@ void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                                   const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
-void launch_render_backward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
-                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                  float* dL_daa_face_verts, const uint32_t* hit_valid, hipStream_t st);
 void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
@@ -137,6 +144,9 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                             float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
+void launch_debug_aa_overlap(int variant, int64_t n, const float* tv, const float* te, const uint8_t* tz, const float* tr,
+                             const float* tn, const float* tc, const float* pixmin, float* area, float* grad, int32_t* code,
+                             hipStream_t st);
 void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,
                    LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
 

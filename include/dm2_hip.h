@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DM2_ABI_VERSION 1
+#define DM2_ABI_VERSION 2
 #define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
 
 /* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
@@ -72,7 +72,8 @@ typedef struct dm2_render_desc {
 
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
-    DM2_SCRATCH_FACE = 0,     /* count = B*F                       */
+    DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 1 for Renderer (holds the packed face records, 256 B per
+                                 (view, face), that forward AND backward read), 0 for LayeredRenderer */
     DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
     DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
     DM2_SCRATCH_LAYER_IMAGE = 3 /* count = B*H*W, aux = B*tiles    */
@@ -94,8 +95,11 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
  * (renderer.cu:185-266, FORWARD::renderCUDA forward.cu:139-432).
  * out_color (B,H,W,3), out_depth (B,H,W): written for every pixel.
  * out_tri_cnt (B,H,W) int32: number of AA records the reference would hold
- * (min(#overlapping faces visited, K)); may be NULL.  The image/binning
- * scratch must be kept (unmodified) for dm2_backward. */
+ * (min(#overlapping faces visited, K)); may be NULL.  The face / binning / image
+ * scratch must be kept (unmodified) for dm2_backward -- they are the three byte
+ * buffers the reference returns and takes back (render.cu:194, render.h:79-81).
+ * The face scratch holds a packed copy of the per-face inputs as the forward saw
+ * them; the backward differentiates with respect to those. */
 int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered,
                     void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes,
@@ -109,6 +113,7 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered,
  * dL_daa_face_verts (B,F,3,2). */
 int dm2_backward(const dm2_render_desc* d, int64_t num_rendered,
                  const float* dL_dout_color, const float* dL_dout_depth,
+                 const void* face_scratch, size_t face_bytes,
                  const void* binning_scratch, size_t binning_bytes,
                  const void* image_scratch, size_t image_bytes,
                  float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity,
@@ -181,6 +186,18 @@ int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc,
  * (N f32), 4 n_contrib (N u32), 5 first_face, 6 first_tet (N i32, layer image scratch). */
 int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
                     const void* scratch, size_t scratch_bytes, void* dst, void* stream);
+
+/* Test hook: run one of the device clippers on n independent (triangle, pixel) pairs.  Tables as the reference's
+ * Triangles builds them (pyrenderer.py:6-30), n x the per-face layout of dm2_render_desc; pixmin (n,2) float: the
+ * pixel's (x, y) origin, unit size.  variant 0: the generic clipper of the per-pixel-walk kernels, area + Jacobian in
+ * the reference's order (aa.h:151-504); 1: the forward's area-only clipper; 2: the forward's accept / reject decision,
+ * then the backward's segment formulation of area + Jacobian.  Outputs: area (n), grad (n,3,2), code (n) int32 --
+ * 0 = no error, non-zero = the reference reports one of its errors E00..E05 (dmesh2_renderer/README.md; the
+ * composite kernels only ever test != 0); area and grad are zero where code != 0. */
+int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, const float* aa_face_edges,
+                         const uint8_t* aa_face_edges_iszero, const float* aa_face_edges_recip,
+                         const float* aa_face_edges_normal, const float* aa_face_edges_normal_c,
+                         const float* pixmin, float* area, float* grad, int32_t* code, void* stream);
 
 /* Optional per-stage timing (bench/profiling only; off by default).  When enabled, the
  * forward/backward/layers entry points record hipEvents on `stream` around every stage of

@@ -59,8 +59,19 @@ def one_case(rng, idx):
         g64 = orc.render_backward_cuda(r64, gc.astype(np.float64), gd.astype(np.float64), nthreads=orc.max_threads())
         e_hip = max(rel_linf(x.cpu().numpy(), g64[n]) for x, n in zip(g, GRAD_NAMES))
         e_orc = max(rel_linf(gref[n], g64[n]) for n in GRAD_NAMES)
-        desc = dict(desc, vs_f32_oracle=worst, hip_vs_f64=e_hip, f32_oracle_vs_f64=e_orc)
-        worst = 0.0 if e_hip <= max(1e-5, 32.0 * e_orc) else e_hip
+        desc = dict(desc, vs_f32_oracle=worst, hip_vs_f64=e_hip, f32_oracle_vs_f64=e_orc, idx=idx)
+        # accepted when the error is summation-order noise.  Exact criterion (small patches): per element within 1e-5 of the
+        # tensor's maximum + 8 eps32 * sum over pixels of |that pixel's contribution| (tests/test_gpu_coverage.py::
+        # test_fuzz4_regression derives it on the one case this sweep ever flagged); large patches: the ratio to the fp32
+        # oracle's own distance from fp64.  The TRUE e_hip stays in the returned worst value either way.
+        accepted = e_hip <= max(1e-5, 32.0 * e_orc)
+        if len(bidx) == 1 and pw * ph <= 4096:
+            from test_gpu_coverage import per_pixel_terms_f64
+            sabs = per_pixel_terms_f64(args, gc, gd, pm, pw, ph)
+            accepted = all((np.abs(x.cpu().numpy() - g64[n]) <= 1e-5 * max(float(np.abs(g64[n]).max()), 1e-12) + 8 * 2.0 ** -24 * sabs[n]).all()
+                           for x, n in zip(g, GRAD_NAMES))
+        desc["accepted_as_summation_noise"] = bool(accepted)
+        return ok, e_hip, desc
     return ok, worst, desc
 
 
@@ -77,12 +88,13 @@ def main():
             n += 1
             if n % 200 == 0:          # a heartbeat: a long silent GPU run is taken to be hung
                 print(f"... {n} cases, {time.time() - t0:.0f} s, worst so far {max(worst_all, worst):.2e}", flush=True)
-            worst_all = max(worst_all, worst)
-            if not ok or worst > 1e-5:
+            worst_all = max(worst_all, worst)             # the true worst error, accepted or not
+            if not ok or (worst > 1e-5 and not desc.get("accepted_as_summation_noise", False)):
                 bad.append((legacy, ok, worst, desc))
                 print("MISMATCH", legacy, ok, worst, desc, flush=True)
     _C.set_flags(0)
-    print(f"{n} cases in {time.time() - t0:.0f} s, worst gradient rel L_inf {worst_all:.2e}, mismatches: {len(bad)}")
+    print(f"{n} cases in {time.time() - t0:.0f} s, worst gradient rel L_inf {worst_all:.2e} (vs the fp64 oracle where it exceeds 1e-5 "
+          f"of the fp32 one), mismatches: {len(bad)}")
     sys.exit(1 if bad else 0)
 
 

@@ -17,9 +17,9 @@
 // Memory pipeline.  A chunk's inputs -- face ids, blend masks, packed face records (dm2_stage.h: 256 B per
 // (view,face), two full lines) -- are requested ONE CHUNK AHEAD, right after the current chunk's cut is known, with
 // LDS-direct loads (global_load_lds_dwordx4: 4 records per wave instruction, no staging registers) into the OTHER
-// half of double-buffered LDS arrays: the global latency is covered by phase B2 of the current chunk instead of
-// stalling the block (in-kernel stamps of the round-1 kernel: 48 % of a block's time went into that stall).  The ids
-// a record address needs are read one chunk earlier still, as a window of 64 entries.
+// half of double-buffered LDS arrays: the global latency is covered by phases B2, C and D of the current chunk instead
+// of stalling the block (in-kernel stamps of the round-1 kernel: 48 % of a block's time went into that stall).  The
+// ids a record address needs are read one chunk earlier still, as a window of 64 entries.
 //
 // The masks are only valid when this frame's forward was dm2_forward_queue.hip (hit_valid[0] == 2); otherwise the
 // kernel returns at once and k_render_backward, launched behind it, does the work.
@@ -45,16 +45,6 @@ constexpr int REC_CHUNKS = (int)(sizeof(FaceRec) / 16);   // 15 x 16 B of the 25
 
 struct __attribute__((aligned(16))) BmPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BmPair) == 32, "BmPair");
-
-// LDS-direct loads: lane l's 16 (4) bytes at `gsrc` land at lds_base + 16 (4) * l; lds_base must be wave-uniform
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
-}
 
 // index of the n-th (0-based) set bit of m; n < popcount(m)
 __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
@@ -171,8 +161,10 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     };
     if (total > 0) {                                               // first chunk: synchronously
         request_ids(0, 0);
+        lds_prefetch_wait();
         __syncthreads();
         request_chunk(0, 0, s_ids2[0]);
+        lds_prefetch_wait();
     }
 
     STAMP(0)
@@ -207,8 +199,8 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             n = lo;
         }
         const int S = s_base[4 * n];
-        // ---- the next chunk starts at base + n: request it now.  hipcc drains the LDS-direct loads at the next
-        // __syncthreads() (behind phase B2, the longest phase), after which the other buffers hold the next chunk.
+        // ---- the next chunk starts at base + n: request it now; it has phases B2, C and D to arrive (waited for before the
+        // flush, so that the flush's atomics are never waited for)
         if (base + n < total) {
             request_chunk(cur ^ 1, base + n, s_ids + n);
             request_ids(cur ^ 1, base + n);
@@ -418,7 +410,8 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             }
         }
         STAMP(9)
-        __syncthreads();
+        lds_prefetch_wait();                                        // the next chunk's records, masks and ids are in LDS ...
+        __syncthreads();                                            // ... for every wave once all of them are here
         STAMP(10)
 
         // ---- flush: lane = (entry, component); 8 entries per pass ------------------------------

@@ -26,18 +26,18 @@
 namespace dm2 {
 
 #ifndef DM2_FQ_CHUNK
-#define DM2_FQ_CHUNK 52
+#define DM2_FQ_CHUNK 32       // 8 LDS-direct wave instructions of 4 records each
 #endif
 #ifndef DM2_FQ_BLOCKS
-#define DM2_FQ_BLOCKS 4       // resident blocks per CU the register budget is set for.  A/B at cfg4 on MI355X: 4 blocks / 52
-                              // faces / 768 pairs / 512 records (38.5 KB, 109 VGPRs) 0.79 ms; 5 blocks (96 VGPRs, no
-                              // spill) need smaller chunks: 36 faces / 384 records 0.91, 30 / 256 0.95; 6 blocks 0.94
+#define DM2_FQ_BLOCKS 4       // resident blocks per CU the register / LDS budget is set for.  A/B at cfg4 on MI355X with the LDS-direct
+                              // prefetch: 3 blocks (512 records, 42.7 KB) 1.01 ms; 4 blocks (416 records, 40.4 KB) 0.83 ms; 4 blocks /
+                              // 384 records / 640 pairs 0.86; 4 blocks / 28 faces 0.87
 #endif
 #ifndef DM2_FQ_PAIRCAP
 #define DM2_FQ_PAIRCAP 768
 #endif
 #ifndef DM2_FQ_SURVCAP
-#define DM2_FQ_SURVCAP 512
+#define DM2_FQ_SURVCAP 416
 #endif
 constexpr int FQ_CHUNK = DM2_FQ_CHUNK;
 constexpr int FQ_PAIRCAP = DM2_FQ_PAIRCAP;
@@ -47,7 +47,8 @@ constexpr int FQ_SURVCAP = DM2_FQ_SURVCAP;
 #endif
 constexpr int FQ_TAILMIN = DM2_FQ_TAILMIN;
 constexpr int FQ_QCAP = ((FQ_PAIRCAP + 3) / 4 + 63) & ~63;     // queue region of one wave
-static_assert(FQ_CHUNK <= 64, "one mask bit per staged face");
+static_assert(FQ_CHUNK <= 32, "one mask bit per staged face; the record prefetch covers 32 records; the id window 64 entries");
+constexpr int FQ_REC_CHUNKS = (int)(sizeof(FaceRec) / 16);
 static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
 static_assert(FQ_PAIRCAP < 65536, "16-bit slots");
 
@@ -61,7 +62,8 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
                        int32_t* __restrict__ out_tri_cnt, uint64_t* __restrict__ hit_masks,
                        uint32_t* __restrict__ hit_valid STAMP_PARAM) {
-    __shared__ FaceRec recs[FQ_CHUNK];
+    __shared__ FaceRec recs2[2][FQ_CHUNK];               // [buffer]: this chunk's faces / the next chunk's (LDS-direct prefetch)
+    __shared__ uint32_t s_ids2[2][64];                   // [buffer]: face ids of the list entries [base, base + 64)
     __shared__ FqPair s_pair[FQ_SURVCAP];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ int s_off[FQ_CHUNK + 1];
@@ -74,15 +76,19 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
     __shared__ unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
 
-    const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    uint32_t tile;
+    if (!tile_of_block(gx * gy * (uint32_t)d.B, tile)) return;    // XCD-contiguous tile order (dm2_pairs.h)
+    const int b = (int)(tile / (gx * gy));
+    const uint32_t tyx = tile - (uint32_t)b * gx * gy;
+    const int tile_y = (int)(tyx / gx), tile_x = (int)(tyx - (uint32_t)tile_y * gx);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     STAMP_DECL
     fill_inv_table(s_inv);
     s_mask[tid] = 0;
-    if (hit_valid && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) hit_valid[0] = 2u;   // AA blend masks are current
+    if (hit_valid && blockIdx.x == 0 && tid == 0) hit_valid[0] = 2u;   // AA blend masks are current
     const int lx = tid & 15, ly = tid >> 4;
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const int X0 = tile_x * TILE, Y0 = tile_y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
     const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
     const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
@@ -97,9 +103,33 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
         }
     }
-    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    const uint4* const grecs = is.face_recs + (int64_t)b * d.F * FACE_REC_U4;
+    // Memory pipeline (see dm2_backward_mask.hip, dm2_stage.h): the next chunk's packed face records and the id window
+    // behind them go straight from global memory into the other LDS buffer while this chunk computes.  The request is
+    // issued at the chunk's TOP, before its own cuts are known, for the entries [base + 32, base + 64): chunks are rarely
+    // cut (a chunk of 32 faces holds ~550 pairs / ~350 survivors at the BASELINE workload against caps of 768 / 512); when
+    // one was, the next chunk finds the wrong entries in its buffer and loads its own synchronously.
+    const int rl = lane / FQ_REC_CHUNKS, rp = lane - rl * FQ_REC_CHUNKS;
+    auto request_ids = [&](int buf, int nb) {
+        if (wid == 2 && nb + lane < total) glds4(face_list + range.x + nb + lane, &s_ids2[buf][0]);
+    };
+    auto request_recs = [&](int buf, int nb, const uint32_t* ids) {
+        const int nc2 = min(FQ_CHUNK, total - nb);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r0 = (i * 4 + wid) * 4, r = r0 + rl;
+            if (rl < 4 && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rp, &recs2[buf][r0]);
+        }
+    };
+    if (total > 0) {
+        request_ids(0, 0);
+        lds_prefetch_wait();
+        __syncthreads();
+        request_recs(0, 0, s_ids2[0]);
+    }
+    int pref_base = 0;                                             // first list entry of what was requested into the next buffer
     const float temp = d.aa_temperature;
     const bool use_aa = temp > 0.0f;
     const float pix_area = 1.0f;
@@ -112,16 +142,31 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     int rec_cnt = 0;
 
     STAMP(0)
-    int n = 0;
-    for (int base = 0; base < total; base += n) {
-        if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260; also fences LDS reuse
+    int n = 0, cur = 0;
+    for (int base = 0; base < total; base += n, cur ^= 1) {
+        lds_prefetch_wait();                                        // this wave's part of buffer `cur` has landed ...
+        if (__syncthreads_count(done) == TILE_PIX) break;          // ... everyone's; forward.cu:258-260; fences LDS reuse
         STAMP(1)
+        FaceRec* const recs = recs2[cur];
+        const uint32_t* const s_ids = s_ids2[cur];
+        if (pref_base != base) {                                   // the previous chunk was cut: the speculation missed
+            request_ids(cur, base);
+            lds_prefetch_wait();
+            __syncthreads();
+            request_recs(cur, base, s_ids);
+            lds_prefetch_wait();
+            __syncthreads();
+        }
+        pref_base = base + FQ_CHUNK;
+        if (pref_base < total) {                                   // lands while this chunk computes
+            request_recs(cur ^ 1, pref_base, s_ids + FQ_CHUNK);
+            request_ids(cur ^ 1, pref_base);
+        }
         // ---- phase A ----------------------------------------------------------------------
         n = min(FQ_CHUNK, total - base);
         const bool last_chunk = base + n >= total;
         int cnt = 0;
         if (tid < n) {
-            stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + base + tid], recs[tid]);
             uint32_t rect;
             cnt = face_pixel_rect(recs[tid].aa.bb, use_aa, X0a, Y0a, xlim, ylim, rect);
             s_rect[tid] = rect;
@@ -291,9 +336,9 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
                                  uint32_t* hit_valid, hipStream_t st) {
-    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    const uint32_t Tn = (uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B);
     StageTimer tm(ST_FWD, st);
-    hipLaunchKernelGGL(k_render_forward_queue, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt,
+    hipLaunchKernelGGL(k_render_forward_queue, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt,
                        hit_masks, hit_valid STAMP_ARG(0));
 }
 

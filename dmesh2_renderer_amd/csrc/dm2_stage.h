@@ -38,6 +38,31 @@ __device__ __forceinline__ void stage_face(const uint4* __restrict__ recs, int64
     for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
 }
 
+// LDS-direct loads (global_load_lds_*): lane l's 16 (4) bytes at `gsrc` land at lds_base + 16 (4) * l; lds_base must be
+// wave-uniform.  Written as inline assembly ON PURPOSE: hipcc tracks an LDS-direct load issued through its builtin as a
+// pending LDS write and puts `s_waitcnt vmcnt(0)` in front of the next LDS read of ANY array and of every barrier, which
+// turns the prefetch into a synchronous copy.  Issued this way the load is invisible to the compiler's wait-count pass;
+// the kernels wait for it themselves (lds_prefetch_wait(), then a workgroup barrier) before they read the destination
+// buffer.  Such a kernel must not spill: a scratch reload would have to wait for every load issued before it.
+// (M0 holds the destination; it is compiler-reserved, hence saved and restored inside the statement.)
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    const uint32_t dst = lds_offset_of(lds_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
+    const uint32_t dst = lds_offset_of(lds_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// wait for every LDS-direct load this wave issued (a workgroup barrier must follow before another wave's part is read)
+__device__ __forceinline__ void lds_prefetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Gather face `face_id` of view `b` from the op's input tensors into `r` (the preprocess kernel packs with it).
 __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
     const int v0 = d.faces[3 * face_id], v1 = d.faces[3 * face_id + 1], v2 = d.faces[3 * face_id + 2];

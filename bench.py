@@ -11,8 +11,10 @@ over the SURVEY §8(d) synthetic scene, inputs resident in HBM.  The Python host
 (projection, AA tables, rays) runs once outside the timed region, as §8(d) prescribes.
 
 N > 1: the same 1080p frame is sharded by 16-pixel tile rows over the ranks
-(dmesh2_renderer_amd.sharding) with ONE all-reduce of the packed gradients per step
-=> "scaling": "strong".
+(dmesh2_renderer_amd.sharding); every rank ends the step with the full gradients of the
+leaves => "scaling": "strong".  `python bench.py --gpus N` starts the N ranks itself
+(a child `torch.distributed.run`, before this process touches the GPU); under an
+external launcher (WORLD_SIZE set) it is one of the ranks.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
 `roofline` (dominant kernel, algorithmic bytes / live hipEvent duration) and
@@ -131,6 +133,41 @@ def host_prep_ms(cfg, device, iters=10):
     return res
 
 
+def end_to_end_ms(cfg, device, iters=10):
+    """What an unmodified caller of the module pays per training step: Renderer.forward (host prep + op) + loss.backward()
+    all the way to verts / verts_color / faces_opacity / faces_intense, with the default (fused) host prep and with the
+    reference-shaped torch prep.  Reported next to the metric, never in `value`."""
+    import dmesh2_renderer_amd as dm2
+    from dmesh2_renderer_amd import scenes
+    W, H, F, ci = CONFIGS[cfg]
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci).to(device)
+    g = torch.Generator().manual_seed(scenes.SEED_BASE + 100 + ci)
+    wc = torch.randn((1, H, W, 3), generator=g).to(device); wd = torch.randn((1, H, W), generator=g).to(device)
+    pm = torch.zeros((1, 2), dtype=torch.int64, device=device)
+    res = {}
+    for name, fused in (("fused_prep", True), ("torch_prep", False)):
+        r = dm2.Renderer(sc.mv, sc.proj, W, H, device, fused_prep=fused)
+        leaves = [sc.verts.clone().requires_grad_(True), sc.verts_color.clone().requires_grad_(True),
+                  sc.faces_opacity.clone().requires_grad_(True), sc.faces_intense.clone().requires_grad_(True)]
+
+        def one():
+            for t in leaves:
+                t.grad = None
+            color, depth = r([0], pm, W, H, leaves[0], sc.faces, leaves[1], leaves[2], leaves[3], sc.background, aa_temperature=AA_TEMPERATURE)
+            ((color * wc).sum() + (depth * wd).sum()).backward()
+
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        torch.cuda.synchronize(device)
+        res[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+        del r
+    return res
+
+
 def point_sampled_ms(cfg, device, steps=5):
     """SURVEY.md 8(d) asks for the aa_temperature = 0 figure next to the headline one: same frame, same faces,
     point-sampled coverage (no AA), forward+backward ms per step.  Reported in `config`, never in `value`."""
@@ -157,11 +194,10 @@ def point_sampled_ms(cfg, device, steps=5):
     return round((time.perf_counter() - t0) / steps * 1e3, 4)
 
 
-def cpu_baseline(args, dLc, dLd, W, H, budget_rows=None):
-    """Oracle (CPU port) on a band of the frame: same faces, `rows` pixel rows in the middle."""
+def _cpu_leg(args, dLc, dLd, W, H, rows, nthreads):
+    """Oracle (CPU port) forward + backward on `rows` pixel rows in the middle of the frame, `nthreads` OpenMP threads."""
     from oracle import cpu as orc
-    nthreads = orc.max_threads()
-    rows = min(budget_rows or 128, H)
+    rows = min(rows, H)
     y0 = max(((H // 2 - rows // 2) // 16) * 16, 0)
     a = [x.detach().cpu().numpy() if torch.is_tensor(x) else x for x in args]
     a[1] = a[1].copy(); a[1][:, 1] += y0
@@ -174,12 +210,53 @@ def cpu_baseline(args, dLc, dLd, W, H, budget_rows=None):
     orc.render_backward_cuda(f, gc, gd, nthreads=nthreads)
     t2 = time.perf_counter()
     npx = rows * W
-    return {
-        "value": round(npx / (t2 - t0) / 1e6, 4), "unit": "Mpixels/s", "cores": nthreads, "kind": "port",
-        "sample": f"rows [{y0},{y0 + rows}) of the {W}x{H} frame ({npx} px, all {a[5].shape[0]} faces binned; "
-                  f"band has {f.num_rendered} tile-face pairs); fwd {t1 - t0:.2f} s + bwd {t2 - t1:.2f} s wall, OpenMP over tiles",
-        "fwd_s": round(t1 - t0, 3), "bwd_s": round(t2 - t1, 3),
+    return {"value": round(npx / (t2 - t0) / 1e6, 4), "unit": "Mpixels/s", "cores": nthreads, "fwd_s": round(t1 - t0, 3),
+            "bwd_s": round(t2 - t1, 3), "rows": [y0, y0 + rows], "pixels": npx, "tile_face_pairs": int(f.num_rendered),
+            "grad_Mtris_per_s": round(a[5].shape[0] / (t2 - t1) / 1e6, 4)}
+
+
+def cpu_baseline(args, dLc, dLd, W, H, budget_rows=None, device=None):
+    """the CPU port (the reference has no CPU path) on this host's cores, in the same run: the BASELINE
+    workload on all cores and on one thread (a bounded band: one thread needs ~1 min for the whole frame), and
+    BASELINE configs[1] (512x512 / 50 k) on all cores and on one thread."""
+    from oracle import cpu as orc
+    nthreads = orc.max_threads()
+    main = _cpu_leg(args, dLc, dLd, W, H, budget_rows or 1088, nthreads)
+    one = _cpu_leg(args, dLc, dLd, W, H, 32, 1)
+    out = {
+        "value": main["value"], "unit": "Mpixels/s", "cores": nthreads, "kind": "port",
+        "sample": f"rows [{main['rows'][0]},{main['rows'][1]}) of the {W}x{H} frame ({main['pixels']} px, all {args[5].shape[0]} faces binned; "
+                  f"band has {main['tile_face_pairs']} tile-face pairs); fwd {main['fwd_s']:.2f} s + bwd {main['bwd_s']:.2f} s wall, OpenMP over tiles",
+        "fwd_s": main["fwd_s"], "bwd_s": main["bwd_s"], "grad_Mtris_per_s": main["grad_Mtris_per_s"],
+        "one_thread": {k: one[k] for k in ("value", "unit", "cores", "fwd_s", "bwd_s", "rows", "pixels")},
     }
+    if device is not None:
+        try:
+            a2, c2, d2, (W2, H2, F2) = build_inputs("cfg2", device, 0, 1)
+            out["cfg2_512x512_50k"] = {"all_threads": _cpu_leg(a2, c2, d2, W2, H2, H2, nthreads), "one_thread": _cpu_leg(a2, c2, d2, W2, H2, H2, 1)}
+        except Exception as ex:      # the baseline legs never take the bench line down
+            out["cfg2_512x512_50k"] = {"error": repr(ex)[:200]}
+    return out
+
+
+VALU_PEAK_GINSTR_PER_S_PER_SIMD = 1.05   # measured on this part (tools/calib/valu_calib.hip, profiles/r02_valu_calibration.jsonl):
+                                         # independent v_add / v_mul wave64 instructions, >= 2 waves per SIMD; = 2.3 cycles at 2.4 GHz
+                                         # (one wave alone: 0.48; v_fma 0.83; DPP / v_min3 / v_bcnt 0.57; IEEE fp32 divide 0.056)
+
+
+def self_launch(opt, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process group (torch.distributed.run) before
+    this process has touched the GPU, pass its output through and exit with its code."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()                       # does not initialise the GPU runtime
+    if opt.gpus > ndev and os.environ.get("DM2_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {opt.gpus}: only {ndev} GPU(s) visible (DM2_BENCH_SINGLE_DEVICE=1 rehearses N ranks on one)")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -197,9 +274,13 @@ def main():
     global AA_TEMPERATURE
     AA_TEMPERATURE = opt.aa_temperature
 
+    if "WORLD_SIZE" not in os.environ and opt.gpus > 1:
+        sys.exit(self_launch(opt, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if opt.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {opt.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product has no CPU path)")
     # rehearsal knobs (one-GPU boxes): DM2_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, DM2_BENCH_BACKEND=gloo
@@ -209,35 +290,67 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    backend = os.environ.get("DM2_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DM2_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
     from dmesh2_renderer_amd import _C
-    from dmesh2_renderer_amd.sharding import BandShardedOp
+    from dmesh2_renderer_amd.sharding import BandShardedOp, sparse_exchange_bytes
     _C.load_library()
     args, dLc, dLd, (W, H, F) = build_inputs(opt.config, device, rank, world)
     op = BandShardedOp(args, world, rank)
     dLc_b = dLc[:, op.y0:op.y0 + op.rows].contiguous()
     dLd_b = dLd[:, op.y0:op.y0 + op.rows].contiguous()
 
-    # N > 1: "leaves" (default) all-reduces only the gradients of the leaves -- [dverts | dverts_color | dfaces_opacity
-    # | dfaces_intense], 80 MB at cfg4 -- after pushing this rank's dverts_ndc / daa_face_verts partials through the fused
-    # host-prep backward locally (sharding.BandShardedOp.backward_leaves); "op6" all-reduces the op's six gradient
-    # tensors (140 MB, SURVEY 8(e) as written).  Both leave every rank with the full gradients of the leaves.
-    reduce_mode = os.environ.get("DM2_BENCH_REDUCE", "leaves")
+    # N > 1, what crosses the links (DM2_BENCH_REDUCE):
+    #   "sparse" (default)  leaf gradients, touched rows only: all-to-all to the row owners + all-gather of the reduced slices
+    #   "leaves"            leaf gradients, ONE dense all-reduce of 24P + 4F + 4BF bytes (80 MB at cfg4)
+    #   "op6"               the op's six gradient tensors, one dense all-reduce (140 MB; SURVEY 8(e) as written)
+    # All three leave every rank with the full gradients; "sparse"/"leaves" push this rank's dverts_ndc / daa_face_verts
+    # partials through the fused host-prep backward locally first (sharding.BandShardedOp.backward_leaves).
+    reduce_mode = os.environ.get("DM2_BENCH_REDUCE", "sparse")
+    if backend != "nccl" and reduce_mode == "sparse" and world > 1 and device.type == "cuda":
+        reduce_mode = "leaves"                             # gloo has no all-to-all on device tensors
     sc = _LAST["scene"]
     prep_inputs = (args[4], args[5], sc.mv[[0]].contiguous(), sc.proj[[0]].contiguous(), W, H)
+    ev_x = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    exch_ms = []
 
-    def step():
+    def step(timed_exchange=False):
         op.forward()
-        if world > 1 and reduce_mode == "leaves":
-            return op.backward_leaves(dLc_b, dLd_b, prep_inputs)
-        return op.backward(dLc_b, dLd_b)
+        if world == 1:
+            return op.backward(dLc_b, dLd_b)
+        if reduce_mode == "op6":
+            g = op.backward(dLc_b, dLd_b, reduce=False)
+            if timed_exchange:
+                ev_x[0].record()
+            from dmesh2_renderer_amd.sharding import allreduce_packed_grads
+            g = allreduce_packed_grads(g)
+            if timed_exchange:
+                ev_x[1].record(); ev_x[1].synchronize(); exch_ms.append(ev_x[0].elapsed_time(ev_x[1]))
+            return g
+        if not timed_exchange:
+            return op.backward_leaves(dLc_b, dLd_b, prep_inputs, exchange="sparse" if reduce_mode == "sparse" else "dense")
+        # same step with events around the exchange: local part first (forward done above)
+        old_ws, op.world_size = op.world_size, 1
+        try:
+            leaves = op.backward_leaves(dLc_b, dLd_b, prep_inputs)
+        finally:
+            op.world_size = old_ws
+        ev_x[0].record()
+        if reduce_mode == "sparse":
+            from dmesh2_renderer_amd.sharding import reduce_leaves_sparse
+            out = reduce_leaves_sparse(*leaves, args[5], op.touched_faces())
+        else:
+            span = torch.cat([t.reshape(-1) for t in leaves])
+            dist.all_reduce(span)
+            out = span
+        ev_x[1].record(); ev_x[1].synchronize(); exch_ms.append(ev_x[0].elapsed_time(ev_x[1]))
+        return out
 
     def barrier():
         if world > 1:
@@ -247,9 +360,13 @@ def main():
     for _ in range(opt.warmup):
         step()
     barrier()
+    # the timed region: exactly `steps` steps between two barriers; per-step hipEvents ride along for the median
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(opt.steps)]
     t0 = time.perf_counter()
-    for _ in range(opt.steps):
+    for i in range(opt.steps):
+        evs[i][0].record()
         step()
+        evs[i][1].record()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -257,9 +374,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt / opt.steps * 1e3
+    ev_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    ms_median = ev_ms[len(ev_ms) // 2] if ev_ms else 0.0
 
     # per-stage hipEvent timing of the same step (separate passes so the events do not perturb `value`)
-    stage_ms = {}
     _C.profile_enable(True)
     acc = {}
     reps = max(3, min(10, opt.steps))
@@ -269,6 +387,9 @@ def main():
             acc.setdefault(k, []).append(v)
     _C.profile_enable(False)
     stage_ms = {k: float(np.median(v)) for k, v in acc.items()}
+    if world > 1:
+        for _ in range(reps):
+            step(timed_exchange=True)
 
     R = op.fwd[0] if op.fwd is not None else 0
     B, P = args[8].shape[0], args[4].shape[0]
@@ -278,53 +399,60 @@ def main():
     dom = max(("forward_composite", "backward_composite"), key=lambda k: stage_ms.get(k, 0.0))
     dom_ms = stage_ms.get(dom, 0.0)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    kname = "k_render_backward" if dom == "backward_composite" else "k_render_forward"
-    traffic, traffic_src, valu_util = None, None, None
+    kname = "k_render_backward_mask" if dom == "backward_composite" else "k_render_forward_queue"
+    traffic, traffic_src, valu_util, valu_note = None, None, None, None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same kernel + config only
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("config") == opt.config and world == 1 and kname in tj:
-            traffic = int((tj[kname]["fetch_kb"] + tj[kname]["write_kb"]) * 1024)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if tj.get("config") == opt.config and world == 1 and AA_TEMPERATURE == 1.0 and kname in tj:
+            # gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide coalesced reads (MI355X_MICROARCH.md, HBM/rocprofv3);
+            # both readings are kept in the json, the corrected one is reported here
+            traffic = int(tj[kname]["hbm_bytes_corrected"])
             if "sq_insts_valu" in tj[kname] and dom_ms > 0:
-                # what actually bounds the kernel: share of VALU issue cycles, from the committed
-                # SQ_INSTS_VALU count of this kernel and the launch time measured in this run
-                valu_util = tj[kname]["sq_insts_valu"] * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3)
-            traffic_src = "profiles/r01_traffic.json (FETCH_SIZE + WRITE_SIZE, raw; see its note on the gfx950 correction)"
+                valu_util = tj[kname]["sq_insts_valu"] / (1024 * VALU_PEAK_GINSTR_PER_S_PER_SIMD * 1e9 * dom_ms * 1e-3)
+                valu_note = (f"SQ_INSTS_VALU {tj[kname]['sq_insts_valu']:.4g} per launch (profiles/r02_traffic.json) / (1024 SIMDs x "
+                             f"{VALU_PEAK_GINSTR_PER_S_PER_SIMD} G wave-instr/s measured by tools/calib/valu_calib.hip x launch time)")
+            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)"
     except (OSError, ValueError, KeyError):
         pass
     roofline = {
         "bound": "hbm", "kernel": kname,
         "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": round(achieved / (HBM_PEAK / 1e9), 5), "traffic": traffic, "traffic_source": traffic_src,
-        "valu_issue_util": None if valu_util is None else round(valu_util, 4),
+        "valu_issue_util": None if valu_util is None else round(valu_util, 4), "valu_issue_util_how": valu_note,
         "alg_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_ms, 4),
         "frame_alg_bytes": alg["frame"], "frame_frac": round(alg["frame"] / (ms_step * 1e-3) / HBM_PEAK, 5),
     }
 
     if rank == 0:
         tri_cnt = op.fwd[5] if op.fwd is not None else None
+        bwd_ms = max(stage_ms.get("backward_composite", 0.0), 1e-9)
+        cfg = {
+            "workload": f"Renderer forward+backward {W}x{H}, {F} triangles (soup, P=3F), B=1, aa_temperature={AA_TEMPERATURE}, K=20, "
+                        f"AA visibility gradients on ({'BASELINE configs[3]' if opt.config == 'cfg4' else opt.config})",
+            "sharding": "single GPU" if world == 1 else f"tile-row bands x{world}, exchange={reduce_mode}",
+            "num_rendered_rank0": int(R), "grad_Mtris_per_s": round(F / bwd_ms / 1e3, 2),
+            "ms_per_step_median_hipevent_rank0": round(ms_median, 4),
+            "stage_ms_rank0": {k: round(v, 4) for k, v in stage_ms.items()},
+            "aa_records_per_pixel_rank0": round(float(tri_cnt.float().mean().item()), 3) if tri_cnt is not None else None,
+        }
+        if world > 1:
+            cfg["exchange_ms_rank0"] = round(float(np.median(exch_ms)), 4) if exch_ms else None
+            nf = int(op.touched_faces().sum().item()) if op.fwd is not None else 0
+            cfg["exchange_bytes_sent_per_rank"] = sparse_exchange_bytes(P, F, B, world, nf, 3 * nf if P == 3 * F else min(P, 3 * nf))
+            cfg["grad_Mtris_per_s"] = round(F / (ms_step * 1e-3) / 1e6, 2)     # whole job: every face's gradient per step
         out = {
             "metric": "Mpixels/s fwd+bwd @1080p/1M tris" if (opt.config == "cfg4" and AA_TEMPERATURE == 1.0) else f"Mpixels/s fwd+bwd ({opt.config})",
             "value": round(W * H / (ms_step * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"Renderer forward+backward {W}x{H}, {F} triangles (soup, P=3F), B=1, aa_temperature={AA_TEMPERATURE}, K=20, "
-                            f"AA visibility gradients on ({'BASELINE configs[3]' if opt.config == 'cfg4' else opt.config})",
-                "sharding": (f"tile-row bands x{world}, " + ("one all-reduce of the leaf gradients (24P+4F+4BF bytes; dverts_ndc / "
-                                                             "daa_face_verts partials go through the fused prep backward locally)"
-                                                             if reduce_mode == "leaves" else "one all-reduce of the six packed op gradients"))
-                            if world > 1 else "single GPU",
-                "num_rendered_rank0": int(R), "grad_Mtris_per_s": round(F / max(stage_ms.get("backward_composite", 0.0), 1e-9) / 1e3, 2),
-                "stage_ms_rank0": {k: round(v, 4) for k, v in stage_ms.items()},
-                "aa_records_per_pixel_rank0": round(float(tri_cnt.float().mean().item()), 3) if tri_cnt is not None else None,
-            },
-            "roofline": roofline,
+            "config": cfg, "roofline": roofline,
         }
         if world == 1 and not opt.no_cpu:
-            out["config"]["host_prep_ms_not_in_value"] = host_prep_ms(opt.config, device)
+            cfg["host_prep_ms_not_in_value"] = host_prep_ms(opt.config, device)
+            cfg["end_to_end_ms_not_in_value"] = end_to_end_ms(opt.config, device)
             if AA_TEMPERATURE == 1.0:
-                out["config"]["ms_per_step_at_aa_temperature_0"] = point_sampled_ms(opt.config, device)
-            out["cpu_baseline"] = cpu_baseline(args, dLc, dLd, W, H, opt.cpu_rows)
+                cfg["ms_per_step_at_aa_temperature_0"] = point_sampled_ms(opt.config, device)
+            out["cpu_baseline"] = cpu_baseline(args, dLc, dLd, W, H, opt.cpu_rows, device)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -28,6 +28,7 @@ _lock = threading.Lock()
 
 DM2_FLAG_CORRECTED_DV = 1
 DM2_FLAG_LEGACY_KERNELS = 2
+DM2_FLAG_NO_BACKWARD = 4
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE = 0, 1, 2, 3
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
@@ -236,6 +237,25 @@ def _tiles(B, W, H):
     return B * ((W + 15) // 16) * ((H + 15) // 16)
 
 
+_tls = threading.local()
+
+
+class forward_only:
+    """``with _C.forward_only(True): _C.render_forward_cuda(...)`` -- no backward will follow this forward (RenderFunction
+    sets it when no input requires a gradient, e.g. under ``torch.no_grad()``): the blend masks a backward would use are
+    not written.  A side channel on purpose: the function keeps the reference's exact 21-argument signature."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = getattr(_tls, "forward_only", False)
+        _tls.forward_only = self.on
+
+    def __exit__(self, *exc):
+        _tls.forward_only = self.old
+
+
 def render_forward_cuda(*args):
     """(num_rendered, color, depth, oarea, tri_id, tri_cnt, doarea, face_buffer, binning_buffer, img_buffer).
 
@@ -250,6 +270,8 @@ def render_forward_cuda(*args):
     lib = load_library()
     keep: list = []
     d, dev, (B, P, F, W, H, K) = _make_desc(args, keep)
+    if getattr(_tls, "forward_only", False):
+        d.flags |= DM2_FLAG_NO_BACKWARD
     with torch.cuda.device(dev):
         st = _stream(dev)
         f32, i32 = torch.float32, torch.int32
@@ -410,8 +432,9 @@ def prepare_faces(verts, faces, mv, proj, width, height, tables=True):
         d.aa_face_verts, d.aa_face_edges, d.aa_face_edges_iszero = _ptr(aav), _ptr(aae), _ptr(aaz)
         d.aa_face_edges_recip, d.aa_face_edges_normal, d.aa_face_edges_normal_c = _ptr(aar), _ptr(aan), _ptr(aac)
         outs += [aav, aae, aaz, aar, aan, aac]
-    if lib.dm2_prepare_faces(ctypes.byref(d), _stream(dev)):
-        raise _err(lib, "dm2_prepare_faces")
+    with torch.cuda.device(dev):
+        if lib.dm2_prepare_faces(ctypes.byref(d), _stream(dev)):
+            raise _err(lib, "dm2_prepare_faces")
     return tuple(outs)
 
 
@@ -431,8 +454,9 @@ def prepare_faces_backward(verts, faces, mv, proj, width, height, g_verts_ndc=No
         gs.append(g)
     scratch = torch.empty((d.B * d.P * 2,), dtype=f32, device=dev) if gs[2] is not None else None
     out = torch.empty((d.P, 3), dtype=f32, device=dev)
-    if lib.dm2_prepare_faces_backward(ctypes.byref(d), _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(scratch), _ptr(out), _stream(dev)):
-        raise _err(lib, "dm2_prepare_faces_backward")
+    with torch.cuda.device(dev):
+        if lib.dm2_prepare_faces_backward(ctypes.byref(d), _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(scratch), _ptr(out), _stream(dev)):
+            raise _err(lib, "dm2_prepare_faces_backward")
     return out
 
 
@@ -463,3 +487,10 @@ def debug_aa_overlap(variant, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, pixmin):
         if lib.dm2_debug_aa_overlap(int(variant), n, *[_ptr(t) for t in ts], _ptr(area), _ptr(grad), _ptr(code), _stream(dev)):
             raise _err(lib, "debug_aa_overlap")
     return area, grad, code
+
+
+def touched_faces(face_buf, B, F):
+    """(F) bool: faces binned into at least one tile of at least one view by the forward that produced ``face_buf``
+    (tiles_touched of the face scratch; dm2_debug_fetch item 8).  The sharded exchange sends only those rows."""
+    t = debug_fetch(8, B * F, 1, 0, face_buf, torch.int32, B * F)
+    return (t.view(B, F) != 0).any(dim=0)

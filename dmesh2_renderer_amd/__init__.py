@@ -24,7 +24,11 @@ from .pyrenderer import Triangles
 
 __all__ = ["RenderFunction", "Renderer", "LayeredRenderer", "Triangles"]
 
-_FUSED_PREP_DEFAULT = os.environ.get("DM2_FUSED_PREP", "0") == "1"
+# Host prep of Renderer.forward (projection + the six AA tables): the fused HIP kernels of dmesh2_renderer_amd/prep.py by
+# default on GPU tensors (two kernels each way instead of ~20 torch kernels each way; verts_image differs from the torch
+# GEMM's in the last bit, well inside the 1e-5 of the port's tolerance); DM2_FUSED_PREP=0 or Renderer(fused_prep=False)
+# selects the reference-shaped torch ops.
+_FUSED_PREP_DEFAULT = os.environ.get("DM2_FUSED_PREP", "1") != "0"
 _W_EPS = 1e-4   # |w| clamp of the projection, sign kept (reference __init__.py:254-255)
 
 
@@ -50,7 +54,8 @@ class RenderFunction(torch.autograd.Function):
         if len(inputs) != RenderFunction.N_INPUTS:
             raise TypeError(f"RenderFunction takes {RenderFunction.N_INPUTS} inputs, got {len(inputs)}")
         try:
-            out = _C.render_forward_cuda(*inputs)
+            with _C.forward_only(not any(ctx.needs_input_grad)):
+                out = _C.render_forward_cuda(*inputs)
         except Exception as ex:
             print("\nAn error occured in renderer forward.")
             print(ex)
@@ -100,8 +105,8 @@ class Renderer(torch.nn.Module):
         super().__init__()
         self._setup(mv, proj, width, height, device)
         self.aa_grad_buffer_size = aa_grad_buffer_size
-        # opt-in (not part of the reference's signature): projection + AA tables by the fused HIP prep
-        # (dmesh2_renderer_amd/prep.py) instead of the reference-shaped torch ops below
+        # not part of the reference's signature: projection + AA tables by the fused HIP prep (dmesh2_renderer_amd/prep.py;
+        # the default) or by the reference-shaped torch ops below (False)
         self.fused_prep = _FUSED_PREP_DEFAULT if fused_prep is None else bool(fused_prep)
 
     def _setup(self, mv, proj, width, height, device):
@@ -182,7 +187,7 @@ class Renderer(torch.nn.Module):
         proj = self.proj[batch_mvp_idx]
         ray_o, ray_d = self.select_rays(batch_mvp_idx, batch_patch_min, patch_width, patch_height)
         f32 = torch.float32
-        if getattr(self, "fused_prep", False):
+        if getattr(self, "fused_prep", False) and verts.is_cuda:
             from . import prep
             (verts_ndc, verts_image, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c) = prep.prepare(
                 verts.to(f32), faces.to(torch.int32), mv.to(f32), proj.to(f32), self.width, self.height)
@@ -236,7 +241,7 @@ class LayeredRenderer(Renderer):
         mv = self.mv[batch_mvp_idx]
         proj = self.proj[batch_mvp_idx]
         i32, f32 = torch.int32, torch.float32
-        if getattr(self, "fused_prep", False):
+        if getattr(self, "fused_prep", False) and verts.is_cuda:
             from . import prep
             with torch.no_grad():
                 verts_ndc, verts_image = prep.project(verts.to(f32), faces.to(i32), mv.to(f32), proj.to(f32), self.width, self.height)

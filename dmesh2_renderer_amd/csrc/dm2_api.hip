@@ -313,6 +313,7 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, 
         case 5: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_face; bytes = (size_t)count * 4; break; }
         case 6: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_tet; bytes = (size_t)count * 4; break; }
         case 7: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.ranges; bytes = (size_t)aux * 8; break; }
+        case 8: { auto s = dm2::FaceState::carve(base, count, dm2::scan_temp_bytes(count), aux != 0); src = s.tiles_touched; bytes = (size_t)count * 4; break; }
         default: return fail("dm2_debug_fetch: unknown item");
     }
     if (!scratch && bytes) return fail("dm2_debug_fetch: null scratch");

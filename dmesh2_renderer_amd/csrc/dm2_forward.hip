@@ -109,7 +109,11 @@ void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const 
                            hipStream_t st) {
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         if (d.aa_temperature > 0.0f) {
-            launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, hit_masks, hit_valid, st);
+            // no backward will follow: no blend masks (hit_valid stays 0 from the binning, so a backward that comes
+            // anyway takes the mask-free walk)
+            const bool masks = !(d.flags & DM2_FLAG_NO_BACKWARD);
+            launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, masks ? hit_masks : nullptr,
+                                        masks ? hit_valid : nullptr, st);
             return;
         }
         // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list meets

@@ -286,7 +286,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             if (out.flags) {
                 s_pair[s] = out;
                 atomicOr(&s_mask[q], 1ull << j);
-                if (out.flags & QF_BLEND) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
+                if (hit_masks && (out.flags & QF_BLEND)) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
             }
         }
         STAMP(5)

@@ -18,6 +18,15 @@ every rank are the gradients of the LEAVES (verts, verts_color, faces_opacity, f
 backward locally (it is linear in them, so summing over ranks commutes with it) and only
 ``[dverts | dverts_color | dfaces_opacity | dfaces_intense]`` crosses the links: 24P + 4F + 4BF bytes instead of
 24P + 12BP + 4F + 28BF (80 MB instead of 140 MB at 1080p / 1 M triangles).
+
+``reduce_leaves_sparse`` is the exchange that scales: a rank's partial gradient is non-zero only in the rows of the faces
+its band touched (about 1/N of them, plus the faces that straddle a band edge) and of their vertices.  Rows are owned by
+contiguous id ranges (face f by rank f // ceil(F/N), vertex v by rank v // ceil(P/N)); every rank sends each owner only the
+touched rows of that owner's range (one all-to-all of [id | row] records, about (N-1)/N^2 of the leaf bytes per rank), the
+owner sums them into its dense slice, and one all-gather of the slices leaves every rank with the full gradients -- the
+(N-1)/N of the leaf bytes that any scheme must deliver to a rank that keeps all parameters.  Against a ring all-reduce of the
+dense buffer (2 (N-1)/N of the bytes) that is about half the traffic at N = 8, and both collectives drive all seven xGMI
+links of a GPU at once instead of being bound by one link of a ring.
 """
 from __future__ import annotations
 
@@ -62,6 +71,80 @@ def allreduce_packed_grads(grads, group=None):
         g.copy_(flat[off:off + n].view_as(g)); off += n
         out.append(g)
     return tuple(out)
+
+
+def sparse_exchange_bytes(P: int, F: int, B: int, world_size: int, touched_faces: int, touched_verts: int) -> dict:
+    """Bytes one rank SENDS in ``reduce_leaves_sparse`` and in the dense alternatives (for DESIGN.md / bench lines)."""
+    N = world_size
+    row_f, row_v = 4 * (2 + B), 4 * 7                     # [id | dopacity | dintense(B)],  [id | dverts(3) | dcolor(3)]
+    Fs, Ps = -(-F // N), -(-P // N)
+    a2a = (touched_faces * row_f + touched_verts * row_v) * (N - 1) // N
+    gather = (Fs * 4 * (1 + B) + Ps * 24) * (N - 1)       # the rank's reduced slice goes to N - 1 peers
+    dense = 24 * P + 4 * F + 4 * B * F
+    return dict(all_to_all=a2a, all_gather=gather, sparse_total=a2a + gather, dense_leaf_bytes=dense,
+                dense_ring_allreduce=2 * dense * (N - 1) // N)
+
+
+def reduce_leaves_sparse(dverts, dcolor, dopacity, dintense, faces, touched, group=None):
+    """Sum the leaf gradients over the ranks of ``group``, moving only touched rows (module docstring).
+
+    dverts, dcolor (P,3); dopacity (F); dintense (B,F): this rank's partial gradients; ``faces`` (F,3) integer;
+    ``touched`` (F) bool: faces that may carry a non-zero partial here (a superset is fine; rows of other faces are
+    NOT sent, so it must cover every face with a non-zero row or a non-zero vertex row).
+    Returns new dense (dverts, dcolor, dopacity, dintense), identical on every rank (same summation order everywhere)."""
+    import torch.distributed as dist
+    N = dist.get_world_size(group)
+    dev = dverts.device
+    P, F, B = dverts.shape[0], dopacity.shape[0], dintense.shape[0]
+    Fs, Ps = -(-F // N), -(-P // N)                        # slice sizes (the last slices are padded)
+    f32 = torch.float32
+    fidx = torch.nonzero(touched.reshape(-1), as_tuple=False).flatten()                    # ascending
+    vidx = torch.unique(faces[fidx].reshape(-1).long()) if fidx.numel() else fidx            # ascending
+    # rows with their global id in front (the id's bits travel in a float slot)
+    frow = torch.cat([fidx.to(torch.int32).view(torch.float32).unsqueeze(1), dopacity[fidx].unsqueeze(1),
+                      dintense[:, fidx].t()], dim=1).to(f32)                                # (nf, 2 + B)
+    vrow = torch.cat([vidx.to(torch.int32).view(torch.float32).unsqueeze(1), dverts[vidx], dcolor[vidx]], dim=1).to(f32)   # (nv, 7)
+    bounds_f = torch.arange(0, N + 1, device=dev) * Fs
+    bounds_v = torch.arange(0, N + 1, device=dev) * Ps
+    cf = torch.searchsorted(fidx, bounds_f)                # rows of owner d: [cf[d], cf[d+1])
+    cv = torch.searchsorted(vidx, bounds_v)
+    nf_send = (cf[1:] - cf[:-1]); nv_send = (cv[1:] - cv[:-1])
+    cnt_send = torch.stack([nf_send, nv_send], dim=1).to(torch.int64).contiguous()         # (N, 2)
+    cnt_recv = torch.empty_like(cnt_send)
+    dist.all_to_all_single(cnt_recv, cnt_send, group=group)
+    # split sizes must be host ints: ONE read-back of (what goes where, what comes from where)
+    host = torch.cat([cnt_send.reshape(-1), cnt_recv.reshape(-1), cf.to(torch.int64), cv.to(torch.int64)]).cpu().tolist()
+    cs = [host[2 * d:2 * d + 2] for d in range(N)]
+    cr = [host[2 * N + 2 * d:2 * N + 2 * d + 2] for d in range(N)]
+    cfh, cvh = host[4 * N:4 * N + N + 1], host[4 * N + N + 1:]
+    wf, wv = 2 + B, 7
+    send = torch.cat([torch.cat([frow[cfh[d]:cfh[d + 1]].reshape(-1), vrow[cvh[d]:cvh[d + 1]].reshape(-1)]) for d in range(N)])
+    in_split = [cs[d][0] * wf + cs[d][1] * wv for d in range(N)]
+    out_split = [cr[d][0] * wf + cr[d][1] * wv for d in range(N)]
+    recv = torch.empty((sum(out_split),), dtype=f32, device=dev)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    # owner: sum what arrived (source by source, ascending: the same order on every rank) into the dense slice
+    rank = dist.get_rank(group)
+    slice_f = torch.zeros((Fs, 1 + B), dtype=f32, device=dev)
+    slice_v = torch.zeros((Ps, 6), dtype=f32, device=dev)
+    off = 0
+    for sr in range(N):
+        nf, nv = cr[sr]
+        if nf:
+            blk = recv[off:off + nf * wf].view(nf, wf)
+            slice_f.index_add_(0, blk[:, 0].contiguous().view(torch.int32).long() - rank * Fs, blk[:, 1:])
+        off += nf * wf
+        if nv:
+            blk = recv[off:off + nv * wv].view(nv, wv)
+            slice_v.index_add_(0, blk[:, 0].contiguous().view(torch.int32).long() - rank * Ps, blk[:, 1:])
+        off += nv * wv
+    mine = torch.cat([slice_v.reshape(-1), slice_f.reshape(-1)])
+    full = torch.empty((N * mine.numel(),), dtype=f32, device=dev)
+    dist.all_gather_into_tensor(full, mine, group=group)
+    full = full.view(N, -1)
+    gv = full[:, : Ps * 6].reshape(N * Ps, 6)[:P]
+    gf = full[:, Ps * 6:].reshape(N * Fs, 1 + B)[:F]
+    return gv[:, :3].contiguous(), gv[:, 3:].contiguous(), gf[:, 0].contiguous(), gf[:, 1:].t().contiguous()
 
 
 class BandShardedOp:
@@ -119,7 +202,18 @@ class BandShardedOp:
             grads = allreduce_packed_grads(grads, group)
         return grads
 
-    def backward_leaves(self, dL_dcolor_band, dL_ddepth_band, prep_inputs, group=None, prep_backward=None):
+    def touched_faces(self):
+        """(F) bool: faces this rank's band binned into at least one tile of at least one view (from the forward's face
+        scratch when the backend exposes it; otherwise None)."""
+        if self.fwd is None:
+            return torch.zeros((self.args[5].shape[0],), dtype=torch.bool, device=self.args[5].device)
+        fn = getattr(self._C, "touched_faces", None)
+        if fn is None:
+            return None
+        B, F = self.args[8].shape[0], self.args[5].shape[0]
+        return fn(self.fwd[7], B, F)
+
+    def backward_leaves(self, dL_dcolor_band, dL_ddepth_band, prep_inputs, group=None, prep_backward=None, exchange="dense"):
         """Band gradients -> gradients of the leaves, summed over ranks with ONE all-reduce of 24P + 4F + 4BF bytes.
 
         ``prep_inputs`` = (verts, faces, mv, proj, width, height) of the host prep that produced ``verts_ndc`` /
@@ -134,6 +228,13 @@ class BandShardedOp:
         verts, faces, mv, proj, width, height = prep_inputs
         pb = prep_backward or self._C.prepare_faces_backward
         dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
+        if exchange == "sparse" and self.world_size > 1:
+            touched = self.touched_faces()
+            if touched is None:      # backend without the scratch accessor: any face or vertex row that is not exactly zero
+                fl = faces.long()
+                touched = (dopacity != 0) | (dintense != 0).any(dim=0) | (dverts[fl] != 0).any(dim=2).any(dim=1) | \
+                          (dcolor[fl] != 0).any(dim=2).any(dim=1)
+            return reduce_leaves_sparse(dverts, dcolor, dopacity, dintense, faces, touched, group)
         packed = getattr(dverts, "_dm2_packed", None)
         n_leaf = dverts.numel() + dcolor.numel() + dopacity.numel()
         if packed is not None and packed.numel() >= n_leaf + dintense.numel() and dndc.numel() >= dintense.numel():

@@ -70,6 +70,10 @@ typedef struct dm2_render_desc {
 #define DM2_FLAG_LEGACY_KERNELS 2 /* composite kernels: per-pixel list walk (reference-shaped work distribution)
                                     instead of the dense (pixel,face)-pair kernels; same results, kept for A/B */
 
+#define DM2_FLAG_NO_BACKWARD 4    /* forward only: no backward will follow (inference, torch.no_grad()): the forward skips the per-entry
+                                    blend masks it otherwise leaves for dm2_backward (32 B per list entry).  A backward called
+                                    anyway still works: it takes the mask-free per-pixel walk. */
+
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 1 for Renderer (holds the packed face records, 256 B per
@@ -183,7 +187,8 @@ int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc,
 /* Introspection for tests/bench: copy pieces of the scratch state to caller
  * (device) buffers.  what: 0 ranges (B*tiles*2 u32, from image scratch),
  * 1 face_list (num_rendered u32, from binning scratch), 2 final_T, 3 final_prev_T
- * (N f32), 4 n_contrib (N u32), 5 first_face, 6 first_tet (N i32, layer image scratch). */
+ * (N f32), 4 n_contrib (N u32), 5 first_face, 6 first_tet (N i32, layer image scratch),
+ * 8 tiles_touched (count = B*F u32, from face scratch; aux = the aux of dm2_scratch_bytes). */
 int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
                     const void* scratch, size_t scratch_bytes, void* dst, void* stream);
 

@@ -235,3 +235,33 @@ def test_two_ranks_band_sharded_product_path(tmp_path):
             assert rel_linf(d[f"g{i}"], g[i].cpu().numpy()) <= 1e-5, (r, name)
         for i, ref in enumerate(leaf_ref):
             assert rel_linf(d[f"leaf{i}"], ref) <= 1e-5, (r, "leaf", i)
+
+
+def test_sparse_exchange_on_rccl_single_rank():
+    """The sparse leaf-gradient exchange on device tensors through RCCL (`nccl` backend) with a one-rank group: the
+    collectives it uses (all_to_all_single with split sizes, all_gather_into_tensor) and the device-side packing must
+    reproduce the input exactly.  (World sizes 2 and 3 are covered over gloo in tests/test_sharding.py.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from dmesh2_renderer_amd.sharding import reduce_leaves_sparse
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = torch.Generator().manual_seed(3)
+        P, F, B = 300, 100, 2
+        faces = torch.arange(P, dtype=torch.int32).view(F, 3).cuda()
+        touched = (torch.rand(F, generator=g) < 0.4).cuda()
+        dv = torch.randn(P, 3, generator=g).cuda(); dc = torch.randn(P, 3, generator=g).cuda()
+        do = torch.randn(F, generator=g).cuda(); di = torch.randn(B, F, generator=g).cuda()
+        keep_f = touched.float(); keep_v = touched.repeat_interleave(3).float().unsqueeze(1)
+        dv, dc, do, di = dv * keep_v, dc * keep_v, do * keep_f, di * keep_f         # rows of untouched faces are zero
+        out = reduce_leaves_sparse(dv, dc, do, di, faces, touched)
+        torch.cuda.synchronize()
+        for a, b in zip(out, (dv, dc, do, di)):
+            assert a.shape == b.shape and torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()

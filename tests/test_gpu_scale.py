@@ -265,3 +265,18 @@ def test_sparse_exchange_on_rccl_single_rank():
             assert a.shape == b.shape and torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_touched_faces_accessor_matches_the_lists():
+    """_C.touched_faces (what the sparse exchange sends) == the faces that appear in this forward's tile lists."""
+    from dmesh2_renderer_amd import _C
+    b = _bench()
+    args, dLc, dLd, _ = b.build_inputs("cfg1", torch.device("cuda", 0), 0, 1)
+    a = list(args); a[3] = 64; a[19] = a[19][:, :64].contiguous(); a[20] = a[20][:, :64].contiguous()      # a band: not every face
+    out = _C.render_forward_cuda(*a)
+    B, F = a[8].shape[0], a[5].shape[0]
+    touched = _C.touched_faces(out[7], B, F).cpu().numpy()
+    N, Tn = B * 64 * 256, B * 16 * 4
+    flist = _C.debug_fetch(1, N, Tn, out[0], out[8], torch.int32, out[0]).cpu().numpy()
+    want = np.zeros(F, bool); want[flist] = True
+    assert np.array_equal(touched, want) and 0 < touched.sum() < F

@@ -82,7 +82,6 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ unsigned long long s_hit2[2][BM_SLOTS];         // [buffer][face][wave]: pixels of the wave the face blends into
     __shared__ int s_base[BM_SLOTS + 1];                       // exclusive scan of the hit counts, face-major
-    __shared__ int s_wave[4];
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk with a record for it
     __shared__ uint32_t s_ids2[2][2 * BM_CAND];                // [buffer]: face ids of the walk positions [base, base + 64)
     __shared__ uint32_t s_max_lc;
@@ -166,28 +165,33 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         request_chunk(0, 0, s_ids2[0]);
         lds_prefetch_wait();
     }
+    for (int k = tid; k < BM_CAND * BM_ACC; k += TILE_PIX) acc[k] = 0.f;     // the flush re-zeroes what it consumes
+    __syncthreads();                                                          // chunk 0's inputs and the zeroes are everyone's
 
     STAMP(0)
     int n = 0, cur = 0;
+    // Four workgroup barriers per chunk: behind the scan, behind B2, behind C, behind D.  No barrier between a chunk's
+    // flush and the next chunk's scan: the flush reads recs2[cur] and acc (and zeroes the entries it read), the scan
+    // reads s_hit2[cur ^ 1] (landed and published before the flush) and writes s_base, last read in phase C.
     for (int base = 0; base < total; base += n, cur ^= 1) {
-        __syncthreads();                                            // previous chunk flushed, LDS reusable
         STAMP(1)
         const int nc = min(BM_CAND, total - base);
-        // recs[j] / s_hit[j][.] = walk position base + j (stored by the previous chunk, or by the prologue)
+        // recs[j] / s_hit[j][.] = walk position base + j (requested by the previous chunk, or by the prologue)
         FaceRec* const recs = recs2[cur];
         const unsigned long long* const s_hit = s_hit2[cur];
         const uint32_t* const s_ids = s_ids2[cur];
-        for (int k = tid; k < nc * BM_ACC; k += TILE_PIX) acc[k] = 0.f;
         STAMP(2)
-        __syncthreads();
-        STAMP(3)
-        int Sall;
-        {
-            const int cnt = (tid < nc * 4) ? __popcll(s_hit[tid]) : 0;            // thread = (face, wave), face-major
-            const int ex = block_exclusive_scan(cnt, s_wave, Sall);
-            if (tid <= BM_SLOTS) s_base[tid] = ex;                                // entries behind nc*4 hold the total
+        if (wid == 0) {                                             // wave 0 alone: lane l scans slots 2l, 2l + 1 (face-major)
+            const int c0 = (2 * lane < nc * 4) ? __popcll(s_hit[2 * lane]) : 0;
+            const int c1 = (2 * lane + 1 < nc * 4) ? __popcll(s_hit[2 * lane + 1]) : 0;
+            const int inc = wave_inclusive_scan(c0 + c1);
+            s_base[2 * lane] = inc - c0 - c1;
+            s_base[2 * lane + 1] = inc - c1;
+            if (lane == 63) s_base[BM_SLOTS] = inc;                                // slots behind nc * 4 hold the total
         }
+        STAMP(3)
         __syncthreads();
+        const int Sall = s_base[BM_SLOTS];
         // keep the leading faces whose hits fit one round of 256 lanes (a face has at most 256)
         n = nc;
         if (Sall > TILE_PIX) {
@@ -319,6 +323,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const bool s2 = (l16 >= 2) & (k2 == jkey);
             const bool s4 = (l16 >= 4) & (k4 == jkey);
             const bool s8 = (l16 >= 8) & (k8 == jkey);
+            const float m1 = s1 ? 1.f : 0.f, m2 = s2 ? 1.f : 0.f, m4 = s4 ? 1.f : 0.f, m8 = s8 ? 1.f : 0.f;
             BmPair pr; pr.flags = 0; pr.T = 0.f; pr.dL_dalpha = 0.f; pr.c0 = pr.c1 = pr.c2 = pr.depth = 0.f;
             if (have && blend) pr = s_pair[tid];
             const bool active = (pr.flags & MB_ACTIVE) != 0;
@@ -363,8 +368,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
                     dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
                 }
-#pragma unroll
-                for (int c = 0; c < 14; c++) seg_scan16(g1[c], s1, s2, s4, s8);
+                seg_scan16_n(g1, m1, m2, m4, m8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 12; c++) atomicAdd(arow + M_DC + c, g1[c]);      // M_DC..+8 and M_DZ..+2 are contiguous
@@ -377,8 +381,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 float g2[6];
 #pragma unroll
                 for (int c = 0; c < 6; c++) g2[c] = dL_doarea * dg[c];                   // dL_doarea is 0 on inactive lanes
-#pragma unroll
-                for (int c = 0; c < 6; c++) seg_scan16(g2[c], s1, s2, s4, s8);
+                seg_scan16_n(g2, m1, m2, m4, m8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 6; c++) atomicAdd(arow + M_AA + c, g2[c]);
@@ -401,8 +404,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     g3[3] = dp1.x; g3[4] = dp1.y; g3[5] = dp1.z;
                     g3[6] = dp2.x; g3[7] = dp2.y; g3[8] = dp2.z;
                 }
-#pragma unroll
-                for (int c = 0; c < 9; c++) seg_scan16(g3[c], s1, s2, s4, s8);
+                seg_scan16_n(g3, m1, m2, m4, m8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 9; c++) atomicAdd(arow + M_DV + c, g3[c]);
@@ -418,10 +420,12 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         const int comp = tid & 31;
         if (comp < M_N) {
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
-                const float* a = acc + e * BM_ACC;
-                if (a[M_FLAG] == 0.f) continue;
+                float* a = acc + e * BM_ACC;
+                if (a[M_FLAG] == 0.f) continue;                                   // (the 32 lanes of an entry sit in one wave)
                 const FaceRec& fc = recs[e];
                 const float val = a[comp];
+                a[comp] = 0.f;                                                    // ready for the next chunk
+                if (comp == 0) a[M_FLAG] = 0.f;
                 float* dst;
                 if (comp < M_DC) dst = dL_dverts + 3 * (int64_t)fc.vid[comp / 3] + (comp % 3);
                 else if (comp < M_DZ) dst = dL_dverts_color + 3 * (int64_t)fc.vid[(comp - M_DC) / 3] + ((comp - M_DC) % 3);

@@ -18,4 +18,24 @@ __device__ __forceinline__ void seg_scan16(float& v, bool s1, bool s2, bool s4, 
     t = v + dpp_shr_f<8>(v); v = s8 ? t : v;
 }
 
+// The same segmented scan for N values at once with ONE instruction per value and step: v_fmac_f32 with a DPP source,
+//     v += shifted(v) * mK,      mK = 1.0 where lane l - K continues the lane's run, else 0.0
+// (t * 1.0 + v rounds once, exactly like t + v; lanes shifted in from outside the row read 0).  Inline assembly: the
+// compiler has no pattern that folds a select into a DPP multiply-add.  A DPP read needs two wait states behind the VALU
+// write of its source; the steps of one value are N >= 3 instructions apart, and an s_nop covers the producers.
+// Requires finite values (0 * inf would poison a lane that is not part of the run).
+template <int N>
+__device__ __forceinline__ void seg_scan16_n(float (&g)[N], float m1, float m2, float m4, float m8) {
+    static_assert(N >= 3, "the steps of one value must be at least three instructions apart");
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int c = 0; c < N; c++) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(g[c]) : "v"(m1));
+#pragma unroll
+    for (int c = 0; c < N; c++) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(g[c]) : "v"(m2));
+#pragma unroll
+    for (int c = 0; c < N; c++) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(g[c]) : "v"(m4));
+#pragma unroll
+    for (int c = 0; c < N; c++) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(g[c]) : "v"(m8));
+}
+
 }  // namespace dm2

@@ -26,18 +26,19 @@
 namespace dm2 {
 
 #ifndef DM2_FQ_CHUNK
-#define DM2_FQ_CHUNK 32       // 8 LDS-direct wave instructions of 4 records each
+#define DM2_FQ_CHUNK 52       // staged faces per chunk (LDS-direct: 4 records per wave instruction)
 #endif
 #ifndef DM2_FQ_BLOCKS
-#define DM2_FQ_BLOCKS 4       // resident blocks per CU the register / LDS budget is set for.  A/B at cfg4 on MI355X with the LDS-direct
-                              // prefetch: 3 blocks (512 records, 42.7 KB) 1.01 ms; 4 blocks (416 records, 40.4 KB) 0.83 ms; 4 blocks /
-                              // 384 records / 640 pairs 0.86; 4 blocks / 28 faces 0.87
+#define DM2_FQ_BLOCKS 4       // resident blocks per CU the register / LDS budget is set for.  A/B at cfg4 on MI355X with a double-
+                              // buffered prefetch of 32-face chunks: 3 blocks (512 records, 42.7 KB) 1.01 ms; 4 blocks (416 records,
+                              // 40.4 KB) 0.83 ms; 4 blocks / 384 records / 640 pairs 0.86; 4 blocks / 28 faces 0.87 -- the
+                              // chunk's fixed costs (five barriers, partly filled rounds) outweigh the longer prefetch distance
 #endif
 #ifndef DM2_FQ_PAIRCAP
 #define DM2_FQ_PAIRCAP 768
 #endif
 #ifndef DM2_FQ_SURVCAP
-#define DM2_FQ_SURVCAP 416
+#define DM2_FQ_SURVCAP 512
 #endif
 constexpr int FQ_CHUNK = DM2_FQ_CHUNK;
 constexpr int FQ_PAIRCAP = DM2_FQ_PAIRCAP;
@@ -47,7 +48,7 @@ constexpr int FQ_SURVCAP = DM2_FQ_SURVCAP;
 #endif
 constexpr int FQ_TAILMIN = DM2_FQ_TAILMIN;
 constexpr int FQ_QCAP = ((FQ_PAIRCAP + 3) / 4 + 63) & ~63;     // queue region of one wave
-static_assert(FQ_CHUNK <= 32, "one mask bit per staged face; the record prefetch covers 32 records; the id window 64 entries");
+static_assert(FQ_CHUNK <= 64, "one mask bit per staged face; the id window is one wave wide");
 constexpr int FQ_REC_CHUNKS = (int)(sizeof(FaceRec) / 16);
 static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
 static_assert(FQ_PAIRCAP < 65536, "16-bit slots");
@@ -62,8 +63,8 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
                        int32_t* __restrict__ out_tri_cnt, uint64_t* __restrict__ hit_masks,
                        uint32_t* __restrict__ hit_valid STAMP_PARAM) {
-    __shared__ FaceRec recs2[2][FQ_CHUNK];               // [buffer]: this chunk's faces / the next chunk's (LDS-direct prefetch)
-    __shared__ uint32_t s_ids2[2][64];                   // [buffer]: face ids of the list entries [base, base + 64)
+    __shared__ FaceRec recs[FQ_CHUNK];                   // this chunk's faces; refilled (LDS-direct) behind phase B2, its last reader
+    __shared__ uint32_t s_ids[64];                       // face ids of the NEXT chunk's list entries
     __shared__ FqPair s_pair[FQ_SURVCAP];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ int s_off[FQ_CHUNK + 1];
@@ -106,30 +107,27 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     const uint4* const grecs = is.face_recs + (int64_t)b * d.F * FACE_REC_U4;
-    // Memory pipeline (see dm2_backward_mask.hip, dm2_stage.h): the next chunk's packed face records and the id window
-    // behind them go straight from global memory into the other LDS buffer while this chunk computes.  The request is
-    // issued at the chunk's TOP, before its own cuts are known, for the entries [base + 32, base + 64): chunks are rarely
-    // cut (a chunk of 32 faces holds ~550 pairs / ~350 survivors at the BASELINE workload against caps of 768 / 512); when
-    // one was, the next chunk finds the wrong entries in its buffer and loads its own synchronously.
+    // Memory pipeline (see dm2_backward_mask.hip, dm2_stage.h): packed face records go straight from global memory into
+    // LDS.  Phase B2 is the last reader of a chunk's records, so the NEXT chunk's are requested into the same array right
+    // behind it (its cut is known by then) and land while the pixels blend (phase C) -- no second buffer: 4 blocks per CU
+    // with 52-face chunks.  The ids a record address needs are requested one phase earlier and land during B2.
     const int rl = lane / FQ_REC_CHUNKS, rp = lane - rl * FQ_REC_CHUNKS;
-    auto request_ids = [&](int buf, int nb) {
-        if (wid == 2 && nb + lane < total) glds4(face_list + range.x + nb + lane, &s_ids2[buf][0]);
+    auto request_ids = [&](int nb) {
+        if (wid == 2 && nb + lane < total) glds4(face_list + range.x + nb + lane, &s_ids[0]);
     };
-    auto request_recs = [&](int buf, int nb, const uint32_t* ids) {
+    auto request_recs = [&](int nb) {
         const int nc2 = min(FQ_CHUNK, total - nb);
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int r0 = (i * 4 + wid) * 4, r = r0 + rl;
-            if (rl < 4 && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rp, &recs2[buf][r0]);
+        for (int r0 = 4 * wid; r0 < nc2; r0 += 16) {                // this wave instruction's first record
+            const int r = r0 + rl;
+            if (rl < 4 && r < nc2) glds16(grecs + (int64_t)s_ids[r] * FACE_REC_U4 + rp, &recs[r0]);
         }
     };
     if (total > 0) {
-        request_ids(0, 0);
+        request_ids(0);
         lds_prefetch_wait();
         __syncthreads();
-        request_recs(0, 0, s_ids2[0]);
+        request_recs(0);
     }
-    int pref_base = 0;                                             // first list entry of what was requested into the next buffer
     const float temp = d.aa_temperature;
     const bool use_aa = temp > 0.0f;
     const float pix_area = 1.0f;
@@ -142,26 +140,11 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     int rec_cnt = 0;
 
     STAMP(0)
-    int n = 0, cur = 0;
-    for (int base = 0; base < total; base += n, cur ^= 1) {
-        lds_prefetch_wait();                                        // this wave's part of buffer `cur` has landed ...
+    int n = 0;
+    for (int base = 0; base < total; base += n) {
+        lds_prefetch_wait();                                        // this wave's part of the chunk's records has landed ...
         if (__syncthreads_count(done) == TILE_PIX) break;          // ... everyone's; forward.cu:258-260; fences LDS reuse
         STAMP(1)
-        FaceRec* const recs = recs2[cur];
-        const uint32_t* const s_ids = s_ids2[cur];
-        if (pref_base != base) {                                   // the previous chunk was cut: the speculation missed
-            request_ids(cur, base);
-            lds_prefetch_wait();
-            __syncthreads();
-            request_recs(cur, base, s_ids);
-            lds_prefetch_wait();
-            __syncthreads();
-        }
-        pref_base = base + FQ_CHUNK;
-        if (pref_base < total) {                                   // lands while this chunk computes
-            request_recs(cur ^ 1, pref_base, s_ids + FQ_CHUNK);
-            request_ids(cur ^ 1, pref_base);
-        }
         // ---- phase A ----------------------------------------------------------------------
         n = min(FQ_CHUNK, total - base);
         const bool last_chunk = base + n >= total;
@@ -243,6 +226,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             n = lo; tot = s_off[lo]; S = S2;
         }
 
+        if (base + n < total) request_ids(base + n);               // the next chunk's ids land during B2
         // ---- phase B2: one survivor per lane ------------------------------------------------
         for (int s = tid; s < S; s += TILE_PIX) {
             const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
@@ -290,7 +274,9 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             }
         }
         STAMP(5)
+        lds_prefetch_wait();
         __syncthreads();
+        if (base + n < total) request_recs(base + n);              // B2 was the records' last reader: refill behind it
         // what the backward needs to find its work without re-classifying (dm2_backward_mask.hip): per list entry and
         // wave of the tile's block, the pixels the entry blends into
         if (hit_masks && tid < n * 4) hit_masks[((int64_t)range.x + base + (tid >> 2)) * 4 + (tid & 3)] = s_bmask[tid];

@@ -29,6 +29,7 @@ _lock = threading.Lock()
 DM2_FLAG_CORRECTED_DV = 1
 DM2_FLAG_LEGACY_KERNELS = 2
 DM2_FLAG_NO_BACKWARD = 4
+DM2_FLAG_ANALYTIC_RAYS = 8
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE = 0, 1, 2, 3
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
@@ -40,12 +41,12 @@ _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c
 class RenderDesc(ctypes.Structure):
     _fields_ = [
         ("B", _i32), ("P", _i32), ("F", _i32), ("W", _i32), ("H", _i32), ("K", _i32),
-        ("aa_temperature", ctypes.c_float), ("flags", _i32),
+        ("aa_temperature", ctypes.c_float), ("flags", _i32), ("full_W", _i32), ("full_H", _i32),
         ("background", _vp), ("patch_min", _vp), ("verts", _vp), ("faces", _vp), ("verts_color", _vp),
         ("faces_opacity", _vp), ("verts_ndc", _vp), ("verts_image", _vp), ("faces_intense", _vp),
         ("aa_face_verts", _vp), ("aa_face_edges", _vp), ("aa_face_edges_iszero", _vp),
         ("aa_face_edges_recip", _vp), ("aa_face_edges_normal", _vp), ("aa_face_edges_normal_c", _vp),
-        ("image_ray_o", _vp), ("image_ray_d", _vp),
+        ("image_ray_o", _vp), ("image_ray_d", _vp), ("ray_cam", _vp),
     ]
 
 
@@ -64,6 +65,7 @@ class LayersDesc(ctypes.Structure):
         ("B", _i32), ("P", _i32), ("F", _i32), ("T", _i32), ("W", _i32), ("H", _i32), ("L", _i32), ("flags", _i32),
         ("verts", _vp), ("faces", _vp), ("tets", _vp), ("face_tets", _vp), ("tet_faces", _vp),
         ("face_existence", _vp), ("verts_ndc", _vp), ("verts_image", _vp), ("image_ray_o", _vp), ("image_ray_d", _vp),
+        ("ray_cam", _vp),
     ]
 
 
@@ -118,7 +120,7 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dm2_abi_version() != 2:
+        if lib.dm2_abi_version() != 3:
             raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
         if path is None:
             _lib = lib
@@ -213,7 +215,9 @@ def _make_desc(args, keep):
                   (aa_r, "aa_face_edges_recip"), (aa_n, "aa_face_edges_normal")):
         need(t, (B, F, 3, 2), nm)
     need(aa_c, (B, F, 3), "aa_face_edges_normal_c")
-    need(ray_o, (B, ph, pw, 3), "image_ray_o"); need(ray_d, (B, ph, pw, 3), "image_ray_d")
+    ana = _analytic(B, dev)
+    if ana is None:
+        need(ray_o, (B, ph, pw, 3), "image_ray_o"); need(ray_d, (B, ph, pw, 3), "image_ray_d")
     if temp == 0.0:
         K = 0                                                     # render.cu:141-142
     ts = dict(
@@ -230,6 +234,12 @@ def _make_desc(args, keep):
     d.flags = _flags
     for k, t in ts.items():
         setattr(d, k, t.data_ptr() if t.numel() > 0 else None)
+    if ana is not None:
+        cam, fw, fh = ana
+        keep.append(cam)
+        d.flags |= DM2_FLAG_ANALYTIC_RAYS
+        d.ray_cam, d.full_W, d.full_H = cam.data_ptr(), fw, fh
+        d.image_ray_o = d.image_ray_d = None
     return d, dev, (B, P, F, pw, ph, K)
 
 
@@ -254,6 +264,35 @@ class forward_only:
 
     def __exit__(self, *exc):
         _tls.forward_only = self.old
+
+
+class analytic_rays:
+    """``with _C.analytic_rays(ray_cam, width, height): _C.render_forward_cuda(...)`` (and the matching backward /
+    generate_render_layers call): the primary rays are computed per pixel from ``ray_cam`` (B,32) float32 = inv(mv) then
+    inv(proj) of each rendered view, row-major, for an image of (width, height) -- the operation order of the reference's
+    ``Renderer._init_rays`` -- and the ``image_ray_o`` / ``image_ray_d`` arguments are placeholders of shape (B,0,0,3)
+    that are never read.  A side channel like ``forward_only``: the 21 / 31 / 13-argument
+    signatures stay the reference's."""
+
+    def __init__(self, ray_cam, width, height):
+        self.val = None if ray_cam is None else (ray_cam, int(width), int(height))
+
+    def __enter__(self):
+        self.old = getattr(_tls, "analytic", None)
+        _tls.analytic = self.val
+
+    def __exit__(self, *exc):
+        _tls.analytic = self.old
+
+
+def _analytic(B, dev):
+    a = getattr(_tls, "analytic", None)
+    if a is None:
+        return None
+    cam, w, h = a
+    if cam.dtype != torch.float32 or tuple(cam.shape) != (B, 32) or cam.device != dev:
+        raise RuntimeError(f"analytic_rays: ray_cam must be float32 (B, 32) on {dev}, got {cam.dtype} {tuple(cam.shape)} on {cam.device}")
+    return cam.contiguous(), w, h
 
 
 def render_forward_cuda(*args):
@@ -365,7 +404,8 @@ def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, te
     bad(tuple(face_tets.shape) != (F, 2), "face_tets must have dimensions (F, 2)")
     bad(tuple(tet_faces.shape) != (T, 4), "tet_faces must have dimensions (T, 4)")
     bad(tuple(verts_ndc.shape) != (B, P, 3) or tuple(verts_image.shape) != (B, P, 2), "verts_ndc/verts_image shape mismatch")
-    bad(tuple(image_ray_o.shape) != (B, height, width, 3) or tuple(image_ray_d.shape) != (B, height, width, 3),
+    ana = _analytic(B, dev)
+    bad(ana is None and (tuple(image_ray_o.shape) != (B, height, width, 3) or tuple(image_ray_d.shape) != (B, height, width, 3)),
         "image_ray_o/image_ray_d must have dimensions (B, H, W, 3)")
     ts = dict(verts=_c(verts, f32), faces=_c(faces, i32), tets=_c(tets, i32), face_tets=_c(face_tets, i32),
               tet_faces=_c(tet_faces, i32), face_existence=_c(face_existence, i32), verts_ndc=_c(verts_ndc, f32),
@@ -374,6 +414,12 @@ def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, te
     d.B, d.P, d.F, d.T, d.W, d.H, d.L, d.flags = B, P, F, T, width, height, num_layers, _flags
     for k, t in ts.items():
         setattr(d, k, t.data_ptr() if t.numel() > 0 else None)
+    if ana is not None:
+        if (ana[1], ana[2]) != (width, height):
+            raise RuntimeError("analytic_rays: the image size differs from generate_render_layers_cuda's width / height")
+        d.flags |= DM2_FLAG_ANALYTIC_RAYS
+        d.ray_cam = ana[0].data_ptr()
+        d.image_ray_o = d.image_ray_d = None
     with torch.cuda.device(dev):
         st = _stream(dev)
         cnt = torch.zeros((B, height, width), dtype=i32, device=dev)              # render.cu:437

@@ -53,6 +53,9 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, *inputs):
         if len(inputs) != RenderFunction.N_INPUTS:
             raise TypeError(f"RenderFunction takes {RenderFunction.N_INPUTS} inputs, got {len(inputs)}")
+        # analytic rays (Renderer(analytic_rays=True)): the camera block rides along in the thread-local side channel and is
+        # kept for the backward
+        ctx.analytic = getattr(_C._tls, "analytic", None)
         try:
             with _C.forward_only(not any(ctx.needs_input_grad)):
                 out = _C.render_forward_cuda(*inputs)
@@ -80,9 +83,11 @@ class RenderFunction(torch.autograd.Function):
             inputs[slot] = v
         oarea, tri_id, tri_cnt, doarea, face_buf, binning_buf, image_buf = saved[ctx.n_tensor_in:]
         try:
-            grads = _C.render_backward_cuda(
-                ctx.num_rendered, *inputs, grad_out_color, grad_out_depth,
-                face_buf, binning_buf, image_buf, oarea, tri_id, tri_cnt, doarea)
+            ana = ctx.analytic
+            with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))):
+                grads = _C.render_backward_cuda(
+                    ctx.num_rendered, *inputs, grad_out_color, grad_out_depth,
+                    face_buf, binning_buf, image_buf, oarea, tri_id, tri_cnt, doarea)
         except Exception as ex:
             print("\nAn error occured in renderer backward.")
             print(ex)
@@ -101,8 +106,11 @@ class Renderer(torch.nn.Module):
     precomputed for every camera at construction.
     """
 
-    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20, fused_prep=None):
+    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20, fused_prep=None, analytic_rays=False):
         super().__init__()
+        # not part of the reference's signature: analytic_rays=True keeps no (Bcam,H,W,3) ray tensors (49.8 MB per camera at
+        # 1080p); the kernels compute each pixel's ray from inv(mv), inv(proj) in the operation order of _init_rays
+        self.analytic_rays = bool(analytic_rays)
         self._setup(mv, proj, width, height, device)
         self.aa_grad_buffer_size = aa_grad_buffer_size
         # not part of the reference's signature: projection + AA tables by the fused HIP prep (dmesh2_renderer_amd/prep.py;
@@ -118,7 +126,11 @@ class Renderer(torch.nn.Module):
         self.num_batch = mv.shape[0]
         self.ray_o = None
         self.ray_d = None
-        self._init_rays()
+        if getattr(self, "analytic_rays", False):
+            self.ray_cam = torch.cat((torch.inverse(mv).reshape(-1, 16), torch.inverse(proj).reshape(-1, 16)), dim=1) \
+                .to(device=device, dtype=torch.float32).contiguous()
+        else:
+            self._init_rays()
 
     # -- rays ------------------------------------------------------------------
     def _init_rays(self):
@@ -185,7 +197,19 @@ class Renderer(torch.nn.Module):
         F = faces.shape[0]
         mv = self.mv[batch_mvp_idx]
         proj = self.proj[batch_mvp_idx]
+        f32 = torch.float32
+        if getattr(self, "analytic_rays", False):
+            cams = torch.as_tensor(list(batch_mvp_idx), device=self.ray_cam.device, dtype=torch.long)
+            ray_o = ray_d = torch.empty((B, 0, 0, 3), dtype=f32, device=self.ray_cam.device)      # placeholders, never read
+            with _C.analytic_rays(self.ray_cam[cams].contiguous(), self.width, self.height):
+                return self._forward_with_rays(B, F, mv, proj, ray_o, ray_d, batch_patch_min, patch_width, patch_height, verts, faces,
+                                               verts_color, faces_opacity, faces_intense, background, aa_temperature)
         ray_o, ray_d = self.select_rays(batch_mvp_idx, batch_patch_min, patch_width, patch_height)
+        return self._forward_with_rays(B, F, mv, proj, ray_o, ray_d, batch_patch_min, patch_width, patch_height, verts, faces,
+                                       verts_color, faces_opacity, faces_intense, background, aa_temperature)
+
+    def _forward_with_rays(self, B, F, mv, proj, ray_o, ray_d, batch_patch_min, patch_width, patch_height, verts, faces,
+                           verts_color, faces_opacity, faces_intense, background, aa_temperature):
         f32 = torch.float32
         if getattr(self, "fused_prep", False) and verts.is_cuda:
             from . import prep
@@ -229,8 +253,9 @@ class LayeredRenderer(Renderer):
     which changes nothing observable.)
     """
 
-    def __init__(self, mv, proj, width, height, device, fused_prep=None):
+    def __init__(self, mv, proj, width, height, device, fused_prep=None, analytic_rays=False):
         torch.nn.Module.__init__(self)
+        self.analytic_rays = bool(analytic_rays)
         self._setup(mv, proj, width, height, device)
         self.fused_prep = _FUSED_PREP_DEFAULT if fused_prep is None else bool(fused_prep)
 
@@ -247,6 +272,13 @@ class LayeredRenderer(Renderer):
                 verts_ndc, verts_image = prep.project(verts.to(f32), faces.to(i32), mv.to(f32), proj.to(f32), self.width, self.height)
         else:
             verts_ndc, verts_image = self.compute_verts_ndc_image(verts, mv, proj)
+        if getattr(self, "analytic_rays", False):
+            cams = torch.as_tensor(list(batch_mvp_idx), device=self.ray_cam.device, dtype=torch.long)
+            ph = torch.empty((len(cams), 0, 0, 3), dtype=f32, device=self.ray_cam.device)
+            with _C.analytic_rays(self.ray_cam[cams].contiguous(), self.width, self.height):
+                return _C.generate_render_layers_cuda(
+                    self.width, self.height, verts.to(f32), faces.to(i32), tets.to(i32), face_tets.to(i32), tet_faces.to(i32),
+                    faces_existence.to(i32), verts_ndc.to(f32), verts_image.to(f32), ph, ph, num_layers)
         ray_o, ray_d = self.ray_o[batch_mvp_idx], self.ray_d[batch_mvp_idx]
         return _C.generate_render_layers_cuda(
             self.width, self.height,

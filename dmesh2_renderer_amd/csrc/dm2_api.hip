@@ -59,6 +59,10 @@ int check_render_desc(const dm2_render_desc* d) {
     if (gx > 0xFFFF || gy > 0xFFFF) return fail("patch too large: more than 65535 tiles per axis");
     if (d->B > 65535) return fail("more than 65535 views per call");
     if ((int64_t)d->B * gx * gy >= (1ll << 31)) return fail("too many tiles");
+    if (d->flags & DM2_FLAG_ANALYTIC_RAYS) {
+        if (!d->ray_cam && d->B > 0) return fail("DM2_FLAG_ANALYTIC_RAYS needs ray_cam");
+        if (d->full_W <= 0 || d->full_H <= 0) return fail("DM2_FLAG_ANALYTIC_RAYS needs the full image size");
+    }
     return 0;
 }
 
@@ -212,6 +216,7 @@ static int check_layers_desc(const dm2_layers_desc* d) {
     const int64_t gx = (d->W + dm2::TILE - 1) / dm2::TILE, gy = (d->H + dm2::TILE - 1) / dm2::TILE;
     if (gx > 0xFFFF || gy > 0xFFFF || d->B > 65535) return fail("image too large");
     if ((int64_t)d->B * gx * gy >= (1ll << 31)) return fail("too many tiles");
+    if ((d->flags & DM2_FLAG_ANALYTIC_RAYS) && !d->ray_cam && d->B > 0) return fail("DM2_FLAG_ANALYTIC_RAYS needs ray_cam");
     return 0;
 }
 

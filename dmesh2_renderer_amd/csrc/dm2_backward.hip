@@ -63,8 +63,7 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
     uint32_t last_contributor = 0;
     float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f;
     if (inside) {
-        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+        pixel_ray(d, b, pix, px + pmx, py + pmy, d.full_W, d.full_H, ro, rd);
         T_final = is.final_T[pix]; prev_T_final = is.final_prev_T[pix];
         last_contributor = is.n_contrib[pix];
         dLc0 = dL_dcolor[3 * pix]; dLc1 = dL_dcolor[3 * pix + 1]; dLc2 = dL_dcolor[3 * pix + 2];

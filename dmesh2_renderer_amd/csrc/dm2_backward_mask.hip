@@ -108,11 +108,10 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     uint32_t last_contributor = 0;
     float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f;
     if (inside) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            s_ray[tid * 6 + k] = d.image_ray_o[3 * pix + k];
-            s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
-        }
+        f3 ro, rd;
+        pixel_ray(d, b, pix, px + pmx, py + pmy, d.full_W, d.full_H, ro, rd);
+        s_ray[tid * 6] = ro.x; s_ray[tid * 6 + 1] = ro.y; s_ray[tid * 6 + 2] = ro.z;
+        s_ray[tid * 6 + 3] = rd.x; s_ray[tid * 6 + 4] = rd.y; s_ray[tid * 6 + 5] = rd.z;
         T_final = is.final_T[pix]; prev_T_final = is.final_prev_T[pix];
         last_contributor = is.n_contrib[pix];
         dLc0 = dL_dcolor[3 * pix]; dLc1 = dL_dcolor[3 * pix + 1]; dLc2 = dL_dcolor[3 * pix + 2];

@@ -87,8 +87,7 @@ k_render_backward_point(dm2_render_desc d, const uint2* __restrict__ ranges, con
     uint32_t last_contributor = 0;
     float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f;
     if (inside) {
-        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+        pixel_ray(d, b, pix, px + (uint32_t)d.patch_min[2 * b], py + (uint32_t)d.patch_min[2 * b + 1], d.full_W, d.full_H, ro, rd);
         s_ray[tid * 6] = ro.x; s_ray[tid * 6 + 1] = ro.y; s_ray[tid * 6 + 2] = ro.z;
         s_ray[tid * 6 + 3] = rd.x; s_ray[tid * 6 + 4] = rd.y; s_ray[tid * 6 + 5] = rd.z;
         T_final = is.final_T[pix]; prev_T_final = is.final_prev_T[pix];

@@ -29,6 +29,25 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 
+// ---- primary ray of a pixel, computed instead of read (DM2_FLAG_ANALYTIC_RAYS).  Operation order of the reference's
+// Renderer._init_rays (__init__.py:198-237): pixel centre (x + 0.5) / W * 2 - 1 -> (ndc_x, ndc_y, -1, 1), row vector times
+// inv(proj)^T, times inv(mv)^T (4-term sums in index order: the reference leaves the order to its BLAS), NO perspective
+// divide, origin = inv(mv)[:3, 3], direction = (target - origin) / (|.| + 1e-6).  cam: inv(mv) (16) then inv(proj) (16).
+__device__ __forceinline__ void analytic_ray(const float* __restrict__ cam, float x_abs, float y_abs, float Wf, float Hf, f3& ro, f3& rd) {
+    const float* imv = cam;
+    const float* ipr = cam + 16;
+    const float h[4] = {((x_abs + 0.5f) / Wf * 2.0f) - 1.0f, ((y_abs + 0.5f) / Hf * 2.0f) - 1.0f, -1.0f, 1.0f};
+    float v[4], w[3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = ((h[0] * ipr[4 * j] + h[1] * ipr[4 * j + 1]) + h[2] * ipr[4 * j + 2]) + h[3] * ipr[4 * j + 3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) w[j] = ((v[0] * imv[4 * j] + v[1] * imv[4 * j + 1]) + v[2] * imv[4 * j + 2]) + v[3] * imv[4 * j + 3];
+    ro = {imv[3], imv[7], imv[11]};
+    const f3 dd = {w[0] - ro.x, w[1] - ro.y, w[2] - ro.z};
+    const float len = sqrtf((dd.x * dd.x + dd.y * dd.y) + dd.z * dd.z) + 1e-6f;
+    rd = {dd.x / len, dd.y / len, dd.z / len};
+}
+
 // ---- Moeller-Trumbore without inside test (auxiliary.h:212-243) -------------
 __device__ __forceinline__ bool ray_tri_intersection(f3 ro, f3 rd, f3 p0, f3 p1, f3 p2, f3& tuv) {
     f3 T = ro - p0, E1 = p1 - p0, E2 = p2 - p0;

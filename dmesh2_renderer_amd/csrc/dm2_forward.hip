@@ -35,8 +35,7 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
 
     f3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) {
-        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+        pixel_ray(d, b, pix, px + pmx, py + pmy, d.full_W, d.full_H, ro, rd);
     }
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];

@@ -34,8 +34,7 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
     f3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) {
-        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+        pixel_ray(d, b, pix, px + (uint32_t)d.patch_min[2 * b], py + (uint32_t)d.patch_min[2 * b + 1], d.full_W, d.full_H, ro, rd);
     }
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];

@@ -98,11 +98,10 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const int xlim = min(TILE - 1, d.W - 1 - X0), ylim = min(TILE - 1, d.H - 1 - Y0);
 
     if (inside) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            s_ray[tid * 6 + k] = d.image_ray_o[3 * pix + k];
-            s_ray[tid * 6 + 3 + k] = d.image_ray_d[3 * pix + k];
-        }
+        f3 ro, rd;
+        pixel_ray(d, b, pix, px + pmx, py + pmy, d.full_W, d.full_H, ro, rd);
+        s_ray[tid * 6] = ro.x; s_ray[tid * 6 + 1] = ro.y; s_ray[tid * 6 + 2] = ro.z;
+        s_ray[tid * 6 + 3] = rd.x; s_ray[tid * 6 + 4] = rd.y; s_ray[tid * 6 + 5] = rd.z;
     }
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dm2_device_math.h"
+#include "dm2_stage.h"
 #include "dm2_state.h"
 
 namespace dm2 {
@@ -58,8 +59,7 @@ k_first_intersect(dm2_layers_desc d, const float* __restrict__ min_depths, const
     const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
     f3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) {
-        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+        pixel_ray(d, b, pix, px, py, d.W, d.H, ro, rd);
     }
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
@@ -115,8 +115,8 @@ k_tet_walk(dm2_layers_desc d, const int32_t* __restrict__ first_face, const int3
     const uint32_t px = blockIdx.x * TILE + (tid & 15), py = blockIdx.y * TILE + (tid >> 4);
     if (!((px < (uint32_t)d.W) && (py < (uint32_t)d.H))) return;
     const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
-    const f3 ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
-    const f3 rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+    f3 ro, rd;
+    pixel_ray(d, b, pix, px, py, d.W, d.H, ro, rd);
     int curr_face = first_face[pix], curr_tet = first_tet[pix];
     bool done = (curr_face == -1 || curr_tet == -1);
     int ndone = 0, steps = 0;

@@ -63,6 +63,18 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
 // wait for every LDS-direct load this wave issued (a workgroup barrier must follow before another wave's part is read)
 __device__ __forceinline__ void lds_prefetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Primary ray of patch pixel (px, py) of view b: read from the op's ray tensors, or computed (DM2_FLAG_ANALYTIC_RAYS)
+template <class Desc>
+__device__ __forceinline__ void pixel_ray(const Desc& d, int b, int64_t pix, uint32_t x_abs, uint32_t y_abs, int full_W, int full_H,
+                                          f3& ro, f3& rd) {
+    if (d.flags & DM2_FLAG_ANALYTIC_RAYS) {
+        analytic_ray(d.ray_cam + 32 * b, (float)x_abs, (float)y_abs, (float)full_W, (float)full_H, ro, rd);
+    } else {
+        ro = {d.image_ray_o[3 * pix], d.image_ray_o[3 * pix + 1], d.image_ray_o[3 * pix + 2]};
+        rd = {d.image_ray_d[3 * pix], d.image_ray_d[3 * pix + 1], d.image_ray_d[3 * pix + 2]};
+    }
+}
+
 // Gather face `face_id` of view `b` from the op's input tensors into `r` (the preprocess kernel packs with it).
 __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
     const int v0 = d.faces[3 * face_id], v1 = d.faces[3 * face_id + 1], v2 = d.faces[3 * face_id + 2];

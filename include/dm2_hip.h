@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DM2_ABI_VERSION 2
+#define DM2_ABI_VERSION 3
 #define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
 
 /* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
@@ -44,6 +44,7 @@ typedef struct dm2_render_desc {
     int32_t K;                    /* len_oarea_buffer (forced to 0 when aa_temperature == 0, render.cu:141-142) */
     float aa_temperature;         /* in [0,1] */
     int32_t flags;                /* DM2_FLAG_* */
+    int32_t full_W, full_H;       /* DM2_FLAG_ANALYTIC_RAYS: size of the image the cameras' rays belong to (Renderer.width/height) */
     const float* background;      /* (3) */
     const int32_t* patch_min;     /* (B,2) */
     const float* verts;           /* (P,3) */
@@ -59,8 +60,9 @@ typedef struct dm2_render_desc {
     const float* aa_face_edges_recip;       /* (B,F,3,2) */
     const float* aa_face_edges_normal;      /* (B,F,3,2) */
     const float* aa_face_edges_normal_c;    /* (B,F,3) */
-    const float* image_ray_o;     /* (B,H,W,3) */
-    const float* image_ray_d;     /* (B,H,W,3) */
+    const float* image_ray_o;     /* (B,H,W,3); may be NULL with DM2_FLAG_ANALYTIC_RAYS */
+    const float* image_ray_d;     /* (B,H,W,3); may be NULL with DM2_FLAG_ANALYTIC_RAYS */
+    const float* ray_cam;         /* DM2_FLAG_ANALYTIC_RAYS: (B,32) = inv(mv) then inv(proj) of each view, row-major 4x4 each */
 } dm2_render_desc;
 
 /* flags */
@@ -73,6 +75,12 @@ typedef struct dm2_render_desc {
 #define DM2_FLAG_NO_BACKWARD 4    /* forward only: no backward will follow (inference, torch.no_grad()): the forward skips the per-entry
                                     blend masks it otherwise leaves for dm2_backward (32 B per list entry).  A backward called
                                     anyway still works: it takes the mask-free per-pixel walk. */
+
+#define DM2_FLAG_ANALYTIC_RAYS 8  /* the primary rays are not read from image_ray_o / image_ray_d but computed per pixel from ray_cam
+                                    in the operation order of the reference's Renderer._init_rays (__init__.py:198-237): pixel
+                                    centre -> NDC (x, y, -1, 1) @ inv(proj)^T @ inv(mv)^T, NO perspective divide, direction
+                                    normalised with + 1e-6 on the length.  Saves the two (B,H,W,3) tensors (49.8 MB per camera at
+                                    1080p) and 24 B per pixel of reads in either pass. */
 
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
@@ -128,7 +136,7 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered,
 typedef struct dm2_layers_desc {
     int32_t B, P, F, T;
     int32_t W, H, L;              /* full frame width/height, num_layers */
-    int32_t flags;
+    int32_t flags;                /* DM2_FLAG_ANALYTIC_RAYS */
     const float* verts;           /* (P,3) */
     const int32_t* faces;         /* (F,3) */
     const int32_t* tets;          /* (T,4) */
@@ -137,8 +145,9 @@ typedef struct dm2_layers_desc {
     const int32_t* face_existence;/* (F) */
     const float* verts_ndc;       /* (B,P,3) */
     const float* verts_image;     /* (B,P,2) */
-    const float* image_ray_o;     /* (B,H,W,3) */
-    const float* image_ray_d;     /* (B,H,W,3) */
+    const float* image_ray_o;     /* (B,H,W,3); may be NULL with DM2_FLAG_ANALYTIC_RAYS */
+    const float* image_ray_d;     /* (B,H,W,3); may be NULL with DM2_FLAG_ANALYTIC_RAYS */
+    const float* ray_cam;         /* DM2_FLAG_ANALYTIC_RAYS: (B,32), see dm2_render_desc */
 } dm2_layers_desc;
 
 int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes,

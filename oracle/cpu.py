@@ -119,6 +119,40 @@ def prepare_faces_backward(verts, faces, mv, proj, width, height, g_ndc=None, g_
     return out
 
 
+def analytic_rays(mv, proj, width, height, dtype=np.float32):
+    """Per-pixel primary rays of cameras mv / proj (B,4,4) in closed form: the reference's Renderer._init_rays
+    (__init__.py:198-237) -- pixel centre -> NDC (x, y, -1, 1) @ inv(proj)^T @ inv(mv)^T without perspective divide,
+    direction normalised with + 1e-6 on the length -- with the 4-term sums taken in index order (the reference leaves
+    that order to its BLAS).  -> ray_o, ray_d (B,H,W,3).  The HIP kernels evaluate exactly this per pixel
+    (DM2_FLAG_ANALYTIC_RAYS, csrc/dm2_device_math.h analytic_ray)."""
+    f = dtype
+    imv = np.linalg.inv(np.asarray(mv, np.float64)).astype(f) if dtype == np.float32 else np.linalg.inv(np.asarray(mv, np.float64))
+    ipr = np.linalg.inv(np.asarray(proj, np.float64)).astype(f) if dtype == np.float32 else np.linalg.inv(np.asarray(proj, np.float64))
+    return analytic_rays_from_inverse(imv, ipr, width, height, dtype)
+
+
+def analytic_rays_from_inverse(imv, ipr, width, height, dtype=np.float32):
+    """Same, from inv(mv), inv(proj) as given (B,4,4) -- what `Renderer(analytic_rays=True)` hands to the kernels."""
+    f = dtype
+    imv = np.asarray(imv, f); ipr = np.asarray(ipr, f)
+    B = imv.shape[0]
+    xs = np.arange(width, dtype=f); ys = np.arange(height, dtype=f)
+    hx = ((xs + f(0.5)) / f(width) * f(2.0)) - f(1.0)
+    hy = ((ys + f(0.5)) / f(height) * f(2.0)) - f(1.0)
+    h = [np.broadcast_to(hx[None, None, :], (B, height, width)), np.broadcast_to(hy[None, :, None], (B, height, width)), f(-1.0), f(1.0)]
+    e = lambda m, j, k: m[:, j, k][:, None, None]
+    v = [((h[0] * e(ipr, j, 0) + h[1] * e(ipr, j, 1)).astype(f) + (h[2] * e(ipr, j, 2)).astype(f)).astype(f) + (h[3] * e(ipr, j, 3)).astype(f)
+         for j in range(4)]
+    v = [x.astype(f) for x in v]
+    w = [((v[0] * e(imv, j, 0) + v[1] * e(imv, j, 1)).astype(f) + (v[2] * e(imv, j, 2)).astype(f)).astype(f) + (v[3] * e(imv, j, 3)).astype(f)
+         for j in range(3)]
+    ro = np.stack([np.broadcast_to(e(imv, j, 3), (B, height, width)) for j in range(3)], axis=-1).astype(f)
+    d = np.stack([w[j].astype(f) - ro[..., j] for j in range(3)], axis=-1).astype(f)
+    ln = (np.sqrt(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(f) + (d[..., 2] * d[..., 2]).astype(f)).astype(f)) + f(1e-6)).astype(f)
+    rd = (d / ln[..., None]).astype(f)
+    return np.ascontiguousarray(ro), np.ascontiguousarray(rd)
+
+
 def aa_overlap(tables, idx, pixmin, dtype=np.float32):
     """Overlap of triangle ``idx`` of ``tables`` with the unit pixel at pixmin."""
     suf, ct = ("f32", _c.c_float) if dtype == np.float32 else ("f64", _c.c_double)

@@ -20,14 +20,14 @@ def test_header_symbols_are_bound_and_exported():
     lib = _C.load_library()                       # raises if a declared symbol is missing
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.dm2_abi_version() == 2
+    assert lib.dm2_abi_version() == 3
 
 
 def test_structs_match_header_layout():
-    # 8 x 4-byte scalars followed by 17 / 10 pointers
+    # 10 / 8 x 4-byte scalars followed by 18 / 11 pointers
     import ctypes
-    assert ctypes.sizeof(_C.RenderDesc) == 8 * 4 + 17 * 8
-    assert ctypes.sizeof(_C.LayersDesc) == 8 * 4 + 10 * 8
+    assert ctypes.sizeof(_C.RenderDesc) == 10 * 4 + 18 * 8
+    assert ctypes.sizeof(_C.LayersDesc) == 8 * 4 + 11 * 8
 
 
 def test_cpu_tensors_are_refused():

@@ -101,3 +101,16 @@ def test_autograd_routes_through_host_prep():
                          sc.faces_opacity, sc.faces_intense, sc.background)
         (color.sum() + depth.sum()).backward()
     assert verts.grad is not None and torch.isfinite(verts.grad).all() and verts.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("name", ["boundary_full.npz", "boundary_patch.npz"])
+def test_analytic_rays_match_reference_rays(golden_dir, name):
+    """The closed form the kernels evaluate per pixel under DM2_FLAG_ANALYTIC_RAYS (oracle.cpu.analytic_rays states it in
+    numpy) against the rays the reference's Renderer._init_rays produced (committed fixtures): 1e-6, the rounding of a
+    4x4 product whose summation order the reference leaves to its BLAS."""
+    from oracle import cpu as orc
+    g = np.load(os.path.join(golden_dir, name))
+    ro, rd = orc.analytic_rays(g["in_mv"], g["in_proj"], int(g["width"]), int(g["height"]))
+    assert ro.shape == g["full_ray_o"].shape and rd.shape == g["full_ray_d"].shape
+    assert np.abs(ro - g["full_ray_o"]).max() <= 1e-6
+    assert np.abs(rd - g["full_ray_d"]).max() <= 1e-6

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Shorten rocprofv3 kernel_stats.csv kernel names (template noise) so the summary fits in profiles/."""
 import csv
+import glob
+import os
 import re
 import sys
 
@@ -11,15 +13,20 @@ def short(name: str) -> str:
     return name[:96]
 
 
-def main(src, dst):
+def main(src, dst=None):
+    if os.path.isdir(src):                         # a rocprofv3 -d directory: its kernel_stats.csv
+        found = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True))
+        if not found:
+            raise SystemExit(f"no *kernel_stats.csv under {src}")
+        src = found[0]
     rows = list(csv.reader(open(src)))
-    with open(dst, "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(rows[0])
-        for r in rows[1:]:
-            r[0] = short(r[0])
-            w.writerow(r)
+    f = open(dst, "w", newline="") if dst else sys.stdout
+    w = csv.writer(f)
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        r[0] = short(r[0])
+        w.writerow(r)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:3])

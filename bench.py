@@ -357,6 +357,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_check = None
+    if world > 1 and reduce_mode == "sparse":
+        # one untimed cross-check of the sparse exchange against the dense all-reduce on this very frame: every rank must
+        # end with the same leaf gradients either way (different summation order: 1e-5 of each tensor's maximum).  All
+        # ranks take the same decision (MIN over ranks); a disagreement falls back to the dense exchange and says so.
+        op.forward()
+        sp = op.backward_leaves(dLc_b, dLd_b, prep_inputs, exchange="sparse")
+        de = op.backward_leaves(dLc_b, dLd_b, prep_inputs, exchange="dense")
+        okf = 1.0
+        for a, b in zip(sp, de):
+            tol = 1e-5 * max(float(b.abs().max().item()), 1e-12)
+            if a.shape != b.shape or float((a - b).abs().max().item()) > tol:
+                okf = 0.0
+        okt = torch.tensor([okf], device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        exchange_check = "sparse == dense on every rank" if float(okt.item()) == 1.0 else "sparse != dense: fell back to dense"
+        if float(okt.item()) != 1.0:
+            reduce_mode = "leaves"
+        del sp, de
     for _ in range(opt.warmup):
         step()
     barrier()
@@ -437,6 +456,7 @@ def main():
         }
         if world > 1:
             cfg["exchange_ms_rank0"] = round(float(np.median(exch_ms)), 4) if exch_ms else None
+            cfg["exchange_check"] = exchange_check
             nf = int(op.touched_faces().sum().item()) if op.fwd is not None else 0
             cfg["exchange_bytes_sent_per_rank"] = sparse_exchange_bytes(P, F, B, world, nf, 3 * nf if P == 3 * F else min(P, 3 * nf))
             cfg["grad_Mtris_per_s"] = round(F / (ms_step * 1e-3) / 1e6, 2)     # whole job: every face's gradient per step

@@ -6,8 +6,9 @@
 // nor classifies (pixel,face) pairs, it never meets a clipper error path, and it can size every chunk to exactly
 // one full round:
 //
-//   per chunk (walked back to front): the masks of the next <= 32 entries, scan of their hit counts, keep the
-//   leading entries whose hits fit 256 lanes, then
+//   per chunk (walked back to front): the masks of the next <= 32 entries, scan of their hit counts (every wave for
+//   itself, DPP), keep the leading entries whose hits fit 256 lanes (a ballot), pair lane -> (entry, pixel) through
+//   start marks and a running maximum, then
 //   B2  lane s: its (face, pixel) from the masks; AA area + Jacobian (dm2_clip_seg.h), Moeller-Trumbore, clamp,
 //       coverage, alpha, interpolated colour / depth -> record in LDS
 //   C   pixel p: replay its records back to front (backward.cu:340-405)
@@ -80,8 +81,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ float acc[BM_CAND * BM_ACC];
     __shared__ BmPair s_pair[TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
-    __shared__ unsigned long long s_hit2[2][BM_SLOTS];         // [buffer][face][wave]: pixels of the wave the face blends into
-    __shared__ int s_base[BM_SLOTS + 1];                       // exclusive scan of the hit counts, face-major
+    __shared__ __attribute__((aligned(16))) unsigned long long s_hit2[2][BM_SLOTS];   // [buffer][face][wave]: pixels of the wave the face blends into
+    __shared__ int s_wbase[4][BM_CAND];                        // [wave][face]: pairs in front of slot (face, wave) -- written and read by that wave
+    __shared__ uint32_t s_mark[4][64];                         // [wave][pair lane]: (slot + 1) << 9 | first pair of the slot, where a slot starts
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk with a record for it
     __shared__ uint32_t s_ids2[2][2 * BM_CAND];                // [buffer]: face ids of the walk positions [base, base + 64)
     __shared__ uint32_t s_max_lc;
@@ -169,9 +171,10 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
     STAMP(0)
     int n = 0, cur = 0;
-    // Four workgroup barriers per chunk: behind the scan, behind B2, behind C, behind D.  No barrier between a chunk's
-    // flush and the next chunk's scan: the flush reads recs2[cur] and acc (and zeroes the entries it read), the scan
-    // reads s_hit2[cur ^ 1] (landed and published before the flush) and writes s_base, last read in phase C.
+    // Three workgroup barriers per chunk: behind B2, behind C, behind D.  None between a chunk's flush and the next chunk's
+    // scan + B2: the flush reads recs2[cur] and acc (and zeroes the entries it read); scan and B2 of the next chunk read
+    // s_hit2 / recs2 of the OTHER buffer (landed and published before the flush), per-wave tables (s_wbase, s_mark) and
+    // write s_pair / s_mask, whose last readers sit in front of the barriers behind C and D.
     for (int base = 0; base < total; base += n, cur ^= 1) {
         STAMP(1)
         const int nc = min(BM_CAND, total - base);
@@ -180,35 +183,32 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         const unsigned long long* const s_hit = s_hit2[cur];
         const uint32_t* const s_ids = s_ids2[cur];
         STAMP(2)
-        if (wid == 0) {                                             // wave 0 alone: lane l scans slots 2l, 2l + 1 (face-major)
-            const int c0 = (2 * lane < nc * 4) ? __popcll(s_hit[2 * lane]) : 0;
-            const int c1 = (2 * lane + 1 < nc * 4) ? __popcll(s_hit[2 * lane + 1]) : 0;
-            const int inc = wave_inclusive_scan(c0 + c1);
-            s_base[2 * lane] = inc - c0 - c1;
-            s_base[2 * lane + 1] = inc - c1;
-            if (lane == 63) s_base[BM_SLOTS] = inc;                                // slots behind nc * 4 hold the total
-        }
+        // ---- scan, cut and decode, by every wave for itself (no barrier, no LDS round trips through another wave): lane l
+        // holds the hit words of slots 2l, 2l + 1 (slot = 4 face + pixel wave, i.e. face-major) and their exclusive scan
+        const ulonglong2 hh = reinterpret_cast<const ulonglong2*>(s_hit)[lane];
+        const unsigned long long h0 = (2 * lane < nc * 4) ? hh.x : 0ull, h1 = (2 * lane + 1 < nc * 4) ? hh.y : 0ull;
+        const int c0 = __popcll(h0), c1 = __popcll(h1);
+        const int inc = wave_inclusive_scan(c0 + c1);
+        const int b0 = inc - c0 - c1, b1 = inc - c1;
+        // keep the leading faces whose hits fit one round of 256 lanes (a face has at most 256): lane 2j + 1 holds the count
+        // up to the end of face j
+        n = max(1, __popcll(__ballot((lane & 1) && inc <= TILE_PIX && (lane >> 1) < nc)));
+        const int S = __builtin_amdgcn_readlane(inc, 2 * n - 1);
+        if ((lane & 1) == (wid >> 1)) s_wbase[wid][lane >> 1] = (wid & 1) ? b1 : b0;    // phase C: slot (face, this wave)
+        // pair lane -> slot: every non-empty slot that starts inside this wave's 64 pair lanes leaves a mark at its first
+        // pair; a running maximum spreads it (slots and their first pairs grow together); the slot that covers the wave's
+        // first lane comes from a ballot
+        const int lo_pair = wid * 64;
+        s_mark[wid][lane] = 0u;
+        { const int r0 = b0 - lo_pair, r1 = b1 - lo_pair;
+          if (c0 > 0 && (uint32_t)r0 < 64u) s_mark[wid][r0] = ((uint32_t)(2 * lane + 1) << 9) | (uint32_t)b0;
+          if (c1 > 0 && (uint32_t)r1 < 64u) s_mark[wid][r1] = ((uint32_t)(2 * lane + 2) << 9) | (uint32_t)b1; }
+        uint32_t seed = 0u;
+        { const unsigned long long e0 = __ballot(c0 > 0 && b0 <= lo_pair), e1 = __ballot(c1 > 0 && b1 <= lo_pair);
+          if (e0) { const int l = 63 - __clzll((long long)e0); seed = ((uint32_t)(2 * l + 1) << 9) | (uint32_t)__builtin_amdgcn_readlane(b0, l); }
+          if (e1) { const int l = 63 - __clzll((long long)e1); seed = max(seed, ((uint32_t)(2 * l + 2) << 9) | (uint32_t)__builtin_amdgcn_readlane(b1, l)); } }
+        const uint32_t mk = max(wave_inclusive_max(s_mark[wid][lane]), seed);
         STAMP(3)
-        __syncthreads();
-        const int Sall = s_base[BM_SLOTS];
-        // keep the leading faces whose hits fit one round of 256 lanes (a face has at most 256)
-        n = nc;
-        if (Sall > TILE_PIX) {
-            int lo = 1, hi = nc;                                                  // s_base[4 lo] <= 256 < s_base[4 hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_base[4 * mid] <= TILE_PIX) lo = mid; else hi = mid;
-            }
-            n = lo;
-        }
-        const int S = s_base[4 * n];
-        // ---- the next chunk starts at base + n: request it now; it has phases B2, C and D to arrive (waited for before the
-        // flush, so that the flush's atomics are never waited for)
-        if (base + n < total) {
-            request_chunk(cur ^ 1, base + n, s_ids + n);
-            request_ids(cur ^ 1, base + n);
-        }
-        STAMP(4)
 
         // ---- phase B2: one blending (pixel,face) pair per lane -------------------------------
         const bool have = tid < S;
@@ -218,13 +218,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         int code = 0;
         bool blend = false;
         if (have) {
-            int lo = 0, hi = 4 * n;                                               // s_base[lo] <= tid < s_base[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_base[mid] <= tid) lo = mid; else hi = mid;
-            }
+            const int lo = (int)(mk >> 9) - 1;                                    // the slot of pair tid, first pair mk & 511
             j = lo >> 2;
-            q = ((lo & 3) << 6) + nth_set_bit64(s_hit[lo], tid - s_base[lo]);
+            q = ((lo & 3) << 6) + nth_set_bit64(s_hit[lo], tid - (int)(mk & 511u));
             const FaceRec& fc = recs[j];
             const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pxmax = pxmin + 1;
             const float pymin = (float)(uint32_t)(Y0a + (q >> 4)), pymax = pymin + 1;
@@ -261,6 +257,13 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
         STAMP(5)
         __syncthreads();
+        // ---- the next chunk starts at base + n: request it now (every wave is past the previous chunk's flush, the last
+        // reader of the other buffers); it has phases C and D to arrive (waited for before the flush, so that the flush's
+        // atomics are never waited for)
+        if (base + n < total) {
+            request_chunk(cur ^ 1, base + n, s_ids + n);
+            request_ids(cur ^ 1, base + n);
+        }
         STAMP(6)
 
         // ---- phase C: per-pixel back-to-front replay ------------------------------------------
@@ -274,7 +277,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 if (e >= last_contributor) continue;                              // backward.cu:219-221
                 // slot of (face jj, this pixel): hits before (jj, this wave) + hits of lower pixels of this wave
                 const int t = jj * 4 + wid;
-                BmPair& pr = s_pair[s_base[t] + __popcll(s_hit[t] & ((1ull << lane) - 1ull))];
+                BmPair& pr = s_pair[s_wbase[wid][jj] + __popcll(s_hit[t] & ((1ull << lane) - 1ull))];
                 const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
                 // alpha == 1 exactly (backward.cu:396) is the forward's decision too: only a pixel's LAST contributor can
                 // have it (T drops to 0 and the pixel is done), and then final_T is exactly 0

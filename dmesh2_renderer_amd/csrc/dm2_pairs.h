@@ -62,16 +62,27 @@ __device__ __forceinline__ int face_pixel_rect(const float bb[4], bool use_bbox,
     return (x1 - x0 + 1) * (y1 - y0 + 1);
 }
 
-// Inclusive scan of one int per lane inside a wave.
+// Inclusive scan of one int per lane inside a wave: DPP row shifts inside the 16-lane rows, then row_bcast:15 / row_bcast:31
+// carry the row totals across (gfx9 DPP; ten VALU instructions, no LDS crossbar round trips as __shfl_up would cost).
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-    const int lane = threadIdx.x & 63;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-    }
-    return inc;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1 (lanes shifted in from outside the row read 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1 and 3 take lane 15 of the row before
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2 and 3 take lane 31
+    return v;
+}
+// Inclusive running maximum of one unsigned per lane inside a wave (same network; 0 is the identity).
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t u) {
+    int v = (int)u;                                                       // values stay below 2^31: signed max is the same
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return (uint32_t)v;
 }
 
 // Block-wide exclusive scan of one int per thread (256 threads = 4 waves).

@@ -86,6 +86,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ uint32_t s_mark[4][64];                         // [wave][pair lane]: (slot + 1) << 9 | first pair of the slot, where a slot starts
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk with a record for it
     __shared__ uint32_t s_ids2[2][2 * BM_CAND];                // [buffer]: face ids of the walk positions [base, base + 64)
+    __shared__ float s_pixc[6][TILE_PIX];                      // per pixel, read by phase C only: dL/dcolour, dL/ddepth, final T, T in front of the last contributor
     __shared__ uint32_t s_max_lc;
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -106,8 +107,10 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const int X0a = X0 + (int)pmx, Y0a = Y0 + (int)pmy;
     const bool corrected = (d.flags & DM2_FLAG_CORRECTED_DV) != 0;
 
-    float T_final = 0.f, prev_T_final = 0.f;
     uint32_t last_contributor = 0;
+    float T = 0.f;                                                 // starts as the T in front of the pixel's last contributor
+    {
+    float T_final = 0.f, prev_T_final = 0.f;
     float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f;
     if (inside) {
         f3 ro, rd;
@@ -119,20 +122,25 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         dLc0 = dL_dcolor[3 * pix]; dLc1 = dL_dcolor[3 * pix + 1]; dLc2 = dL_dcolor[3 * pix + 2];
         dLd = dL_ddepth[pix];
     }
-    const uint2 range = ranges[tile];
+    // phase C is their only reader: parked in LDS, not in six registers that would be live across B2 and D
+    s_pixc[0][tid] = dLc0; s_pixc[1][tid] = dLc1; s_pixc[2][tid] = dLc2; s_pixc[3][tid] = dLd;
+    s_pixc[4][tid] = T_final; s_pixc[5][tid] = prev_T_final;
+    T = prev_T_final;
+    }
+    uint2 range = ranges[tile];                                    // block-uniform: keep it in scalar registers
+    range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
 
     if (tid == 0) s_max_lc = 0;
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_lc, last_contributor);
     __syncthreads();
-    const int total = (int)min(s_max_lc, range.y - range.x);       // entries behind every pixel's last contributor are dead
+    const int total = (int)min((uint32_t)__builtin_amdgcn_readfirstlane(s_max_lc), range.y - range.x);   // entries behind every pixel's last contributor are dead
 
     const float temp = d.aa_temperature;                           // > 0 (the launcher dispatches on it)
     const float pix_area = 1.0f;
     const float bg0 = d.background[0], bg1 = d.background[1], bg2 = d.background[2];
     const uint4* const grecs = is.face_recs + (int64_t)b * d.F * FACE_REC_U4;
 
-    float T = prev_T_final;
     bool T_first_pass = true;
     float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_recd = 0.f;
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
@@ -150,14 +158,16 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     // request masks + records of the chunk starting at walk position nb into buffer buf; ids[i]: face id of position nb + i
     auto request_chunk = [&](int buf, int nb, const uint32_t* ids) {
         const int nc2 = min(BM_CAND, total - nb);
+        // (the masks first: should the compiler ever reload an address from scratch here, that reload waits for every
+        // load issued before it -- vmcnt is in order -- and must not find this chunk's record loads in front of it)
+        if (wid == 1 && (lane >> 1) < nc2)                         // lane: masks of (face lane / 2, waves 2 (lane & 1), + 1)
+            glds16(hit_masks + walk_entry(nb + (lane >> 1)) * 4 + (lane & 1) * 2, &s_hit2[buf][0]);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int r0 = (i * 4 + wid) * 4;                      // this wave instruction's first record
             const int r = r0 + rl;
             if (rl < 4 && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rp, &recs2[buf][r0]);
         }
-        if (wid == 1 && (lane >> 1) < nc2)                         // lane: masks of (face lane / 2, waves 2 (lane & 1), + 1)
-            glds16(hit_masks + walk_entry(nb + (lane >> 1)) * 4 + (lane & 1) * 2, &s_hit2[buf][0]);
     };
     if (total > 0) {                                               // first chunk: synchronously
         request_ids(0, 0);
@@ -270,6 +280,11 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         {
             unsigned long long m = s_mask[tid];
             s_mask[tid] = 0;
+            float dLc0 = 0.f, dLc1 = 0.f, dLc2 = 0.f, dLd = 0.f, T_final = 0.f, prev_T_final = 0.f;
+            if (m) {
+                dLc0 = s_pixc[0][tid]; dLc1 = s_pixc[1][tid]; dLc2 = s_pixc[2][tid]; dLd = s_pixc[3][tid];
+                T_final = s_pixc[4][tid]; prev_T_final = s_pixc[5][tid];
+            }
             while (m) {                                                           // ascending face = back to front
                 const int jj = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -419,23 +434,31 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(10)
 
         // ---- flush: lane = (entry, component); 8 entries per pass ------------------------------
+        // Branch-free: every component's destination is  base + 4 (id * mult),  id one of the record's (face_id, vid[0..2]).
         const int comp = tid & 31;
         if (comp < M_N) {
+            const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
+            const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
+            const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
+            const int mult = g < 3 ? 3 : (g == 5 ? 6 : 1);
+            const int64_t add = g < 2 ? (int64_t)(within % 3) : g == 2 ? (int64_t)b * d.P * 3 + 2 : g == 3 ? (int64_t)0
+                              : g == 4 ? (int64_t)b * d.F : (int64_t)b * d.F * 6 + within;
+            float* const basep = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
+                                : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
                 float* a = acc + e * BM_ACC;
-                if (a[M_FLAG] == 0.f) continue;                                   // (the 32 lanes of an entry sit in one wave)
-                const FaceRec& fc = recs[e];
+                const float flag = a[M_FLAG];                                     // (the 32 lanes of an entry sit in one wave)
                 const float val = a[comp];
-                a[comp] = 0.f;                                                    // ready for the next chunk
-                if (comp == 0) a[M_FLAG] = 0.f;
-                float* dst;
-                if (comp < M_DC) dst = dL_dverts + 3 * (int64_t)fc.vid[comp / 3] + (comp % 3);
-                else if (comp < M_DZ) dst = dL_dverts_color + 3 * (int64_t)fc.vid[(comp - M_DC) / 3] + ((comp - M_DC) % 3);
-                else if (comp < M_OP) dst = dL_dverts_ndc + ((int64_t)b * d.P + fc.vid[comp - M_DZ]) * 3 + 2;
-                else if (comp == M_OP) dst = dL_dfaces_opacity + fc.face_id;
-                else if (comp == M_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
-                else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - M_AA);
-                atomicAdd(dst, val);
+                const int id = (&recs[e].face_id)[sel];
+                if (flag != 0.f) {
+                    a[comp] = 0.f;                                                // ready for the next chunk
+                    if (comp == 0) a[M_FLAG] = 0.f;
+#if !defined(DM2_BM_FLUSH_MODE) || DM2_BM_FLUSH_MODE == 0
+                    atomicAdd(basep + (int64_t)id * mult, val);
+#else
+                    if (val == 12345.678f) basep[(int64_t)id * mult] = val;     // timing experiment only: no global traffic
+#endif
+                }
             }
         }
         STAMP(11)

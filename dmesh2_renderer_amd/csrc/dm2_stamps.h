@@ -11,9 +11,18 @@
 namespace dm2 { unsigned long long* stamps_table(); }   // device pointer to [2][DM2_NSTAMP], defined in dm2_api.hip
 #define STAMP_PARAM , unsigned long long* st_out
 #define STAMP_ARG(which) , (dm2::stamps_table() + (which) * DM2_NSTAMP)
-#define STAMP_DECL unsigned long long st_acc[DM2_NSTAMP] = {}; unsigned long long st_last = __builtin_readcyclecounter();
-#define STAMP(i) { const unsigned long long st_now = __builtin_readcyclecounter(); st_acc[i] += st_now - st_last; st_last = st_now; }
-#define STAMP_FLUSH { if ((threadIdx.x & 63) == 0) { for (int s_ = 0; s_ < DM2_NSTAMP; s_++) if (st_acc[s_]) atomicAdd(&st_out[s_], st_acc[s_]); } }
+// The per-segment sums live in LDS (one row per wave, 12 segments) and the last stamp in scalar registers, so that the
+// diagnostic build keeps the product build's VGPR budget: with the sums in VGPRs the backward kernel spilled to scratch,
+// and a scratch reload waits for every outstanding global atomic / LDS-direct load (vmcnt is in order) -- the profile
+// then showed the spills, not the kernel.
+#define DM2_NSTAMP_LDS 12
+#define STAMP_DECL __shared__ unsigned long long st_lds[4][DM2_NSTAMP_LDS]; \
+    if ((threadIdx.x & 63) < DM2_NSTAMP_LDS) st_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0ull; \
+    unsigned long long st_last = __builtin_readcyclecounter();
+#define STAMP(i) { const unsigned long long st_now = __builtin_readcyclecounter(); \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&st_lds[threadIdx.x >> 6][i], st_now - st_last); st_last = st_now; }
+#define STAMP_FLUSH { if ((threadIdx.x & 63) < DM2_NSTAMP_LDS) { const unsigned long long v_ = st_lds[threadIdx.x >> 6][threadIdx.x & 63]; \
+    if (v_) atomicAdd(&st_out[threadIdx.x & 63], v_); } }
 #else
 #define STAMP_PARAM
 #define STAMP_ARG(which)

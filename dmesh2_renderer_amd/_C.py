@@ -74,12 +74,12 @@ EXPORTS = {
     "dm2_abi_version": (ctypes.c_int, []),
     "dm2_last_error": (ctypes.c_char_p, []),
     "dm2_scratch_bytes": (_sz, [ctypes.c_int, _i64, _i64]),
-    "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
-    "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64)]),
-    "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dm2_prepare_faces": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp]),
     "dm2_prepare_faces_backward": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_debug_aa_overlap": (ctypes.c_int, [ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,7 +120,7 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dm2_abi_version() != 3:
+        if lib.dm2_abi_version() != 4:
             raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
         if path is None:
             _lib = lib
@@ -327,14 +327,14 @@ def render_forward_cuda(*args):
             e = _bytes(dev, 0)
             return 0, color, depth, oarea, tri_id, tri_cnt, doarea, e, _bytes(dev, 0), _bytes(dev, 0)
         tri_cnt = torch.empty((B, H, W), dtype=i32, device=dev)
-        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 1))
+        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 2 * Tn + 1))
         img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_IMAGE, N, Tn))
-        nr = _i64(0)
-        if lib.dm2_forward_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr)):
+        nr, longest = _i64(0), _i64(0)
+        if lib.dm2_forward_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr), ctypes.byref(longest)):
             raise _err(lib, "render_forward_cuda (plan)")
         R = int(nr.value)
         bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
-        if lib.dm2_forward_run(ctypes.byref(d), R, _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
+        if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
                                _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st):
             raise _err(lib, "render_forward_cuda (run)")
     return R, color, depth, oarea, tri_id, tri_cnt, doarea, face_buf, bin_buf, img_buf
@@ -427,14 +427,14 @@ def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, te
         N, Tn, BF = B * height * width, _tiles(B, width, height), B * F
         if N == 0:
             return layers, cnt
-        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 0))
+        face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 2 * Tn))
         img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_LAYER_IMAGE, N, Tn))
-        nr = _i64(0)
-        if lib.dm2_layers_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr)):
+        nr, longest = _i64(0), _i64(0)
+        if lib.dm2_layers_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr), ctypes.byref(longest)):
             raise _err(lib, "generate_render_layers_cuda (plan)")
         R = int(nr.value)
         bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
-        if lib.dm2_layers_run(ctypes.byref(d), R, _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
+        if lib.dm2_layers_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
                               _ptr(img_buf), img_buf.numel(), _ptr(layers), _ptr(cnt), st):
             raise _err(lib, "generate_render_layers_cuda (run)")
     generate_render_layers_cuda.last_debug = (R, face_buf, bin_buf, img_buf)      # kept for tests

@@ -41,12 +41,13 @@ struct PinnedWord {     // per-thread pinned staging word for the num_rendered r
 };
 thread_local PinnedWord g_pin;
 
-int read_last_offset(const uint32_t* face_offsets, int64_t BF, hipStream_t st, int64_t* out) {
-    if (BF <= 0) { *out = 0; return 0; }
+// (num_rendered, entries of the longest tile list) of the plan that just ran on `st`: the one host read-back of a forward
+int read_plan_meta(const uint32_t* plan_meta, hipStream_t st, int64_t* num_rendered, int64_t* max_tile_entries) {
     if (!g_pin.p) DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocDefault));
-    DM2_HIP(hipMemcpyAsync(g_pin.p, face_offsets + BF - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DM2_HIP(hipMemcpyAsync(g_pin.p, plan_meta, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DM2_HIP(hipStreamSynchronize(st));
-    *out = (int64_t)*g_pin.p;
+    *num_rendered = (int64_t)g_pin.p[0];
+    if (max_tile_entries) *max_tile_entries = (int64_t)g_pin.p[1];
     return 0;
 }
 
@@ -137,7 +138,7 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
     if (count < 0) count = 0;
     if (aux < 0) aux = 0;
     switch (kind) {
-        case DM2_SCRATCH_FACE: dm2::FaceState::carve(nullptr, count, dm2::scan_temp_bytes(count), aux != 0, &total); break;
+        case DM2_SCRATCH_FACE: dm2::FaceState::carve(nullptr, count, aux >> 1, dm2::scan_temp_bytes(count), (aux & 1) != 0, &total); break;
         case DM2_SCRATCH_IMAGE: dm2::ImageState::carve(nullptr, count, aux, &total); break;
         case DM2_SCRATCH_BINNING: dm2::BinningState::carve(nullptr, count, dm2::sort_temp_bytes(count, aux), &total); break;
         case DM2_SCRATCH_LAYER_IMAGE: dm2::LayerImageState::carve(nullptr, count, aux, &total); break;
@@ -146,21 +147,22 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
     return total;
 }
 
-int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered) {
+int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
+                     int64_t* max_tile_entries) {
     if (check_render_desc(d)) return 1;
-    if (!num_rendered) return fail("num_rendered is null");
+    if (!num_rendered || !max_tile_entries) return fail("num_rendered / max_tile_entries is null");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t BF = (int64_t)d->B * d->F;
-    *num_rendered = 0;
-    if (d->P == 0 || BF == 0) return 0;                                  // render.cu:149
-    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
-    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), true);
+    const int64_t BF = (int64_t)d->B * d->F, Tn = tiles_of(d->B, d->W, d->H);
+    *num_rendered = 0; *max_tile_entries = 0;
+    if (d->P == 0 || BF == 0 || Tn == 0) return 0;                       // render.cu:149
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d, st));
     DM2_HIP(hipGetLastError());
-    return read_last_offset(fs.face_offsets, BF, st, num_rendered);
+    return read_plan_meta(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
 
-int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_scratch, size_t face_bytes,
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
                     float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream) {
     if (check_render_desc(d)) return 1;
@@ -172,12 +174,13 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, void* face_s
     const bool have_faces = (d->P != 0 && BF != 0);
     dm2::BinningState bs{};
     if (have_faces) {
-        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
+        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
         if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
-        dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), true);
+        dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
         is.face_recs = fs.recs;
-        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.depths, fs, bs, is.ranges, st));   // renderer.cu:192
+        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
+                                     fs.depths, fs, bs, is.ranges, st));   // renderer.cu:192
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
@@ -196,13 +199,13 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL
     const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
     if (d->F == 0 || d->P == 0 || N == 0 || num_rendered <= 0) return 0;       // render.cu:320
     const int64_t BF = (int64_t)d->B * d->F;
-    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 1) > face_bytes) return fail("face scratch too small");
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
     dm2::ImageState is = dm2::ImageState::carve(const_cast<void*>(image_scratch), N, Tn);
     dm2::BinningState bs = dm2::BinningState::carve(const_cast<void*>(binning_scratch), num_rendered,
                                                     dm2::sort_temp_bytes(num_rendered, Tn));
-    is.face_recs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, dm2::scan_temp_bytes(BF), true).recs;
+    is.face_recs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, Tn, dm2::scan_temp_bytes(BF), true).recs;
     dm2::launch_render_backward(*d, is.ranges, bs.face_list, is, dL_dout_color, dL_dout_depth, dL_dverts, dL_dverts_color,
                                 dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs.hit_masks, bs.hit_valid, st);
     DM2_HIP(hipGetLastError());
@@ -220,22 +223,23 @@ static int check_layers_desc(const dm2_layers_desc* d) {
     return 0;
 }
 
-int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered) {
+int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
+                    int64_t* max_tile_entries) {
     if (check_layers_desc(d)) return 1;
-    if (!num_rendered) return fail("num_rendered is null");
+    if (!num_rendered || !max_tile_entries) return fail("num_rendered / max_tile_entries is null");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t BF = (int64_t)d->B * d->F;
-    *num_rendered = 0;
-    if (BF == 0) return 0;
-    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
-    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), false);
+    const int64_t BF = (int64_t)d->B * d->F, Tn = tiles_of(d->B, d->W, d->H);
+    *num_rendered = 0; *max_tile_entries = 0;
+    if (BF == 0 || Tn == 0) return 0;
+    if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn) > face_bytes) return fail("face scratch too small");
+    dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), false);
     // patch_min = 0 (renderer.cu:557-558): a null patch_min means "all zeros"
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr, st));
     DM2_HIP(hipGetLastError());
-    return read_last_offset(fs.face_offsets, BF, st, num_rendered);
+    return read_plan_meta(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
 
-int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, void* face_scratch, size_t face_bytes,
+int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
                    void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
                    int32_t* render_layers, int32_t* render_layers_cnt, void* stream) {
     if (check_layers_desc(d)) return 1;
@@ -247,11 +251,12 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, void* face_sc
     dm2::FaceState fs{};
     dm2::BinningState bs{};
     if (BF != 0) {
-        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 0) > face_bytes) return fail("face scratch too small");
+        if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn) > face_bytes) return fail("face scratch too small");
         if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
-        fs = dm2::FaceState::carve(face_scratch, BF, dm2::scan_temp_bytes(BF), false);
+        fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), false);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
-        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, fs.min_depths, fs, bs, ls.ranges, st));   // renderer.cu:603
+        DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
+                                     fs.min_depths, fs, bs, ls.ranges, st));   // renderer.cu:603
     } else {
         DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
@@ -318,7 +323,7 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered, 
         case 5: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_face; bytes = (size_t)count * 4; break; }
         case 6: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.first_tet; bytes = (size_t)count * 4; break; }
         case 7: { auto s = dm2::LayerImageState::carve(base, count, aux); src = s.ranges; bytes = (size_t)aux * 8; break; }
-        case 8: { auto s = dm2::FaceState::carve(base, count, dm2::scan_temp_bytes(count), aux != 0); src = s.tiles_touched; bytes = (size_t)count * 4; break; }
+        case 8: { auto s = dm2::FaceState::carve(base, count, 0, dm2::scan_temp_bytes(count), false); src = s.tiles_touched; bytes = (size_t)count * 4; break; }
         default: return fail("dm2_debug_fetch: unknown item");
     }
     if (!scratch && bytes) return fail("dm2_debug_fetch: null scratch");

@@ -39,7 +39,10 @@ namespace dm2 {
 constexpr int BM_CAND = 32;      // candidate entries per chunk: two per 16-lane group of the cooperative record copy
 static_assert(BM_CAND * 4 <= TILE_PIX && 2 * BM_CAND <= 64, "one scan thread per (face, wave); one id window per wave");
 constexpr int BM_SLOTS = BM_CAND * 4;
-constexpr int BM_ACC = 32;
+#ifndef DM2_BM_ACC
+#define DM2_BM_ACC 33       // odd pitch: the emit lanes of different faces add to different LDS banks (A/B at cfg4: 32 -> 33, -0.4 %)
+#endif
+constexpr int BM_ACC = DM2_BM_ACC;       // pitch of an accumulator row (dwords)
 constexpr int M_DV = 0, M_DC = 9, M_DZ = 18, M_OP = 21, M_IN = 22, M_AA = 23, M_N = 29, M_FLAG = 31;
 constexpr uint32_t MB_BLEND = 1u, MB_ACTIVE = 2u;
 constexpr int REC_CHUNKS = (int)(sizeof(FaceRec) / 16);   // 15 x 16 B of the 256-B global record are live
@@ -87,6 +90,8 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk with a record for it
     __shared__ uint32_t s_ids2[2][2 * BM_CAND];                // [buffer]: face ids of the walk positions [base, base + 64)
     __shared__ float s_pixc[6][TILE_PIX];                      // per pixel, read by phase C only: dL/dcolour, dL/ddepth, final T, T in front of the last contributor
+    __shared__ float* s_fl_base[32];                           // flush, per component: destination of id 0 ...
+    __shared__ int s_fl_sel[32];                               // ... which id of the record (face_id, vid[0..2]) | dwords per id << 2
     __shared__ uint32_t s_max_lc;
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -131,6 +136,18 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
 
     if (tid == 0) s_max_lc = 0;
+    if (tid < M_N) {   // flush table: component tid goes to  base + 4 * (id * mult),  id one of the record's (face_id, vid[0..2])
+        const int comp = tid;
+        const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
+        const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
+        const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
+        const int mult = g < 3 ? 3 : (g == 5 ? 6 : 1);
+        const int64_t add = g < 2 ? (int64_t)(within % 3) : g == 2 ? (int64_t)b * d.P * 3 + 2 : g == 3 ? (int64_t)0
+                          : g == 4 ? (int64_t)b * d.F : (int64_t)b * d.F * 6 + within;
+        s_fl_base[comp] = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
+                          : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
+        s_fl_sel[comp] = sel | (mult << 2);
+    }
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_lc, last_contributor);
     __syncthreads();
@@ -437,14 +454,8 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // Branch-free: every component's destination is  base + 4 (id * mult),  id one of the record's (face_id, vid[0..2]).
         const int comp = tid & 31;
         if (comp < M_N) {
-            const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
-            const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
-            const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
-            const int mult = g < 3 ? 3 : (g == 5 ? 6 : 1);
-            const int64_t add = g < 2 ? (int64_t)(within % 3) : g == 2 ? (int64_t)b * d.P * 3 + 2 : g == 3 ? (int64_t)0
-                              : g == 4 ? (int64_t)b * d.F : (int64_t)b * d.F * 6 + within;
-            float* const basep = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
-                                : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
+            float* const basep = s_fl_base[comp];                                 // (per-component table, filled in the prologue)
+            const int sel = s_fl_sel[comp] & 3, mult = s_fl_sel[comp] >> 2;
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
                 float* a = acc + e * BM_ACC;
                 const float flag = a[M_FLAG];                                     // (the 32 lanes of an entry sit in one wave)

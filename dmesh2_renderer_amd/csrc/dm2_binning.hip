@@ -1,9 +1,22 @@
 // dm2_binning.hip -- face -> 16x16 tile binning for gfx950.
 //
-//   k_preprocess   forward.cu:16-108   one lane per (view,face): depth keys, cull, tile rect
+// What the reference builds (renderer.cu:165-219): per tile, the list of faces whose patch rectangle touches it,
+// ordered by depth key, ties in emission order ((view,face) ascending) -- through one global stable radix sort of
+// (tile | depth bits) keys.  Here the lists are bucketed first and sorted per tile:
+//
+//   plan  k_preprocess   forward.cu:16-108   one lane per (view,face): depth keys, cull, tile rect, packed record;
+//                                            one atomic per touched tile -> entries per tile
+//         k_tile_scan                        exclusive scan of the tile counts: list starts, num_rendered (= the
+//                                            reference's scan of tiles_touched, renderer.cu:165-171), longest list
+//   run   k_bin_scatter  renderer.cu:415-465 (depth bits | face id) keys into the tile's segment, any order
+//         k_tile_sort                        one block per tile: bitonic sort of the segment in LDS (in global memory
+//                                            for a list beyond 2048 entries); the key is unique, and ascending
+//                                            (depth bits, face id) IS the stable radix order; writes face ids + ranges
+//
+// 1M faces / 1.6M entries at 1080p: 0.06 ms against 0.24 ms for emit + six radix passes + range detection.
+// Lists beyond TILE_SORT_MAX entries (a plan result) and DM2_FLAG_LEGACY_KERNELS take the reference's route:
 //   rocPRIM scan   renderer.cu:165-171 inclusive sum of tiles_touched
 //   k_emit_keys    renderer.cu:415-465 (tile | depth bits) keys + face ids, emission order
-//                                      (view,face) ascending, then y, then x
 //   rocPRIM sort   renderer.cu:199-207 stable LSD radix sort on bits [0, 32+msb(B*tiles))
 //   k_tile_ranges  renderer.cu:470-492 [start,end) of every tile in the sorted list
 #include <hip/hip_runtime.h>
@@ -12,6 +25,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dm2_device_math.h"
+#include "dm2_pairs.h"
 #include "dm2_stage.h"
 #include "dm2_state.h"
 
@@ -52,6 +66,12 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
         }
     }
+    if (touched != 0) {                                                    // entries per tile (the lists' sizes)
+        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
+        uint32_t* cnt = fs.tile_cnt + (int64_t)gx * gy * b;
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) atomicAdd(cnt + (y * gx + x), 1u);
+    }
     fs.tiles_touched[idx] = touched;
     fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
     fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
@@ -63,6 +83,123 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
         uint4* dst = fs.recs + idx * FACE_REC_U4;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
+    }
+}
+
+// Exclusive scan of the tile counts (one block; thread i owns a run of consecutive tiles), their sum and maximum.
+__global__ void __launch_bounds__(1024)
+k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ start, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t per = (Tn + 1023) / 1024, t0 = tid * per, t1 = t0 + per < Tn ? t0 + per : Tn;
+    if (tid == 0) s_max = 0;
+    uint32_t sum = 0, mx = 0;
+    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t]; sum += c; mx = mx > c ? mx : c; }
+    const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    if (mx) atomicMax(&s_max, mx);
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t v = s_w[w]; if (w < wid) before += v; total += v; }
+    uint32_t run = before + inc - sum;
+    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t]; start[t] = run; run += c; }
+    __syncthreads();
+    if (tid == 0) { meta[0] = total; meta[1] = s_max; }
+}
+
+// (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count); the position inside
+// the segment is whatever the atomic hands out -- k_tile_sort orders the segment.  ranges[t].y (zeroed) is the fill cursor.
+__global__ void __launch_bounds__(256)
+k_bin_scatter(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ key_depth, FaceState fs,
+              uint2* __restrict__ ranges, uint64_t* __restrict__ keys) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * F) return;
+    if (fs.tiles_touched[idx] == 0) return;
+    const int b = (int)(idx / F), f = (int)(idx % F);
+    const uint32_t lo = fs.rect_lo[idx], hi = fs.rect_hi[idx];
+    const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
+    const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
+    const int64_t tile_base = (int64_t)gx * gy * b;
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x++) {
+            const int64_t t = tile_base + (y * gx + x);
+            keys[fs.tile_start[t] + atomicAdd(&ranges[t].y, 1u)] = key;
+        }
+}
+
+// One block per tile: sort the tile's segment of (depth bits | face id) keys ascending, leave the face ids in face_list and
+// [start, end) in ranges (0,0 for an empty tile, as the reference's zero-filled ranges, renderer.cu:211).
+// The network is the bitonic sorter in its all-ascending form (a merge of size k: mirror exchange i <-> i ^ (k - 1), then
+// half-cleaners i <-> i ^ j, j = k/4 .. 1; the smaller key always goes to the lower index), so a list that is not a power
+// of two long is padded with +inf -- real padding in LDS, virtual (skip exchanges whose upper index is past the end) in
+// global memory.
+constexpr int TILE_SORT_LDS = 2048;
+// pair p of a step: mirror step of a merge of size 2^lk (lk > 0), or half-cleaner at distance 2^lj (lk == 0)
+__device__ __forceinline__ void sort_pair_indices(int p, int lk, int lj, int& i, int& j) {
+    if (lk) { const int blk = p >> (lk - 1), off = p & ((1 << (lk - 1)) - 1); i = (blk << lk) + off; j = (blk << lk) + ((1 << lk) - 1 - off); }
+    else { const int blk = p >> lj, off = p & ((1 << lj) - 1); i = (blk << (lj + 1)) + off; j = i + (1 << lj); }
+}
+// The steps of the network in order: for lk = 1 .. LN: mirror(lk), then half-cleaners lj = lk - 2 .. 0.
+// Pair p is always handled by thread p & 255, so a step whose pairs stay inside 128 consecutive keys (mirror with lk <= 7,
+// half-cleaner with lj <= 5) only touches keys of the thread's own wave: such steps need no workgroup barrier between
+// them, the wave's LDS operations execute in order (a fence keeps the compiler from reordering them).
+__device__ __forceinline__ void sort_step_sync(bool wave_local_next, bool wave_local_this) {
+    if (wave_local_next && wave_local_this) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    else __syncthreads();
+}
+__global__ void __launch_bounds__(256)
+k_tile_sort(int64_t Tn, uint32_t R, const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+            uint32_t* __restrict__ face_list, uint2* __restrict__ ranges, uint32_t* __restrict__ hit_valid) {
+    __shared__ uint64_t s_key[TILE_SORT_LDS];
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t s0 = tile_start[t], e0 = (t + 1 < Tn) ? tile_start[t + 1] : R;
+    const int n = (int)(e0 - s0);
+    if (t == 0 && tid == 0) *hit_valid = 0u;      // new lists: the blend masks of an earlier forward are stale
+    if (tid == 0) ranges[t] = n ? make_uint2(s0, e0) : make_uint2(0u, 0u);
+    if (n == 0) return;
+    uint64_t* const seg = keys + s0;
+    int LN = 0;
+    while ((1 << LN) < n) LN++;
+    const int N = 1 << LN, half = N >> 1;
+    if (n <= TILE_SORT_LDS) {
+        for (int i = tid; i < N; i += 256) s_key[i] = i < n ? seg[i] : ~0ull;
+        __syncthreads();
+        for (int lk = 1; lk <= LN; lk++) {
+            for (int lj = lk - 1; lj >= 0; lj--) {                           // lj == lk - 1: the mirror step of this merge
+                const bool mirror = lj == lk - 1;
+                for (int p = tid; p < half; p += 256) {
+                    int i, j;
+                    sort_pair_indices(p, mirror ? lk : 0, lj, i, j);
+                    const uint64_t a = s_key[i], c = s_key[j];
+                    if (c < a) { s_key[i] = c; s_key[j] = a; }
+                }
+                // span of this step's pairs: 2^(lj+1) keys (mirror: 2^lk = the same); the next step's is at most that,
+                // except for the mirror of the next merge (2^(lk+1))
+                const bool this_local = lj + 1 <= 7;
+                const bool next_local = lj > 0 ? true : (lk + 1 <= 7);
+                sort_step_sync(this_local && next_local, true);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) face_list[s0 + i] = (uint32_t)s_key[i];
+    } else {
+        for (int lk = 1; lk <= LN; lk++) {
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                const bool mirror = lj == lk - 1;
+                for (int p = tid; p < half; p += 256) {
+                    int i, j;
+                    sort_pair_indices(p, mirror ? lk : 0, lj, i, j);
+                    if (j < n) {
+                        const uint64_t a = seg[i], c = seg[j];
+                        if (c < a) { seg[i] = c; seg[j] = a; }
+                    }
+                }
+                __syncthreads();                                              // (block scope: the block's own global writes are visible)
+            }
+        }
+        for (int i = tid; i < n; i += 256) face_list[s0 + i] = (uint32_t)seg[i];
     }
 }
 
@@ -132,26 +269,44 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     const int64_t BF = (int64_t)B * F;
     if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int64_t Tn = (int64_t)B * gx * gy;
     const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
+    hipError_t e = hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
+    if (e != hipSuccess || Tn == 0) return e;
+    e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)Tn * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     if (pack && fs.recs)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
-    size_t bytes = fs.scan_temp_bytes;
-    return rocprim::inclusive_scan(fs.scan_temp, bytes, fs.tiles_touched, fs.face_offsets, (size_t)BF, rocprim::plus<uint32_t>(), st);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_start, fs.plan_meta);
+    return hipSuccess;
 }
 
-hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
-                           uint2* ranges, hipStream_t st) {
+hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
+                           FaceState fs, BinningState bs, uint2* ranges, hipStream_t st) {
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
     hipError_t e = hipMemsetAsync(ranges, 0, (size_t)Tn * sizeof(uint2), st);           // renderer.cu:211
     if (e != hipSuccess || R <= 0) return e;
     const int64_t BF = (int64_t)B * F;
+    if (!legacy && max_tile_entries <= TILE_SORT_MAX) {
+        {
+            StageTimer tm(ST_EMIT, st);
+            hipLaunchKernelGGL(k_bin_scatter, dim3((int)((BF + 255) / 256)), dim3(256), 0, st, B, F, gx, gy, key_depth, fs, ranges, bs.keys);
+        }
+        StageTimer tm(ST_SORT, st);
+        hipLaunchKernelGGL(k_tile_sort, dim3((unsigned)Tn), dim3(256), 0, st, Tn, (uint32_t)R, fs.tile_start, bs.keys, bs.face_list,
+                           ranges, bs.hit_valid);
+        return hipSuccess;
+    }
     {
         StageTimer tm(ST_EMIT, st);
+        size_t bytes = fs.scan_temp_bytes;
+        e = rocprim::inclusive_scan(fs.scan_temp, bytes, fs.tiles_touched, fs.face_offsets, (size_t)BF, rocprim::plus<uint32_t>(), st);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_emit_keys, dim3((int)((BF + 255) / 256)), dim3(256), 0, st, B, F, gx, gy, key_depth, fs,
                            bs.keys_unsorted, bs.face_list_unsorted);
     }

@@ -45,13 +45,18 @@ struct FaceState {
     uint32_t* rect_hi;        // x1 | y1 << 16
     void* scan_temp; size_t scan_temp_bytes;
     uint4* recs;              // (BF, FACE_REC_U4) packed face records; nullptr when the caller needs none (layers)
-    static FaceState carve(void* base, int64_t BF, size_t scan_temp_bytes, bool with_recs, size_t* total = nullptr) {
+    // tile-bucketed binning (dm2_binning.hip): filled by the plan step, consumed by the run step
+    uint32_t* tile_cnt;       // (Tn)  list entries per tile
+    uint32_t* tile_start;     // (Tn)  exclusive scan of tile_cnt
+    uint32_t* plan_meta;      // [0] num_rendered  [1] entries of the longest tile list
+    static FaceState carve(void* base, int64_t BF, int64_t Tn, size_t scan_temp_bytes, bool with_recs, size_t* total = nullptr) {
         Carver c(base); FaceState s;
         s.depths = c.take<float>(BF); s.min_depths = c.take<float>(BF); s.max_depths = c.take<float>(BF);
         s.tiles_touched = c.take<uint32_t>(BF); s.face_offsets = c.take<uint32_t>(BF);
         s.rect_lo = c.take<uint32_t>(BF); s.rect_hi = c.take<uint32_t>(BF);
         s.scan_temp = c.take<char>(scan_temp_bytes); s.scan_temp_bytes = scan_temp_bytes;
         s.recs = with_recs ? c.take<uint4>(BF * FACE_REC_U4) : nullptr;
+        s.tile_cnt = c.take<uint32_t>(Tn); s.tile_start = c.take<uint32_t>(Tn); s.plan_meta = c.take<uint32_t>(4);
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }
@@ -111,14 +116,17 @@ size_t scan_temp_bytes(int64_t BF);
 size_t sort_temp_bytes(int64_t R, int64_t Tn);
 unsigned sort_end_bit(int64_t Tn);
 
-// preprocess + inclusive scan (forward.cu:16-108, renderer.cu:165-171)
+// plan: preprocess (forward.cu:16-108) + entries per tile + their scan -> fs.plan_meta = (num_rendered, longest list)
 // pack != nullptr: also write the packed face records fs.recs from the op's inputs
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
                                   hipStream_t st);
-// key emit + stable sort + tile ranges (renderer.cu:185-219); key depth = depths or min_depths
-hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, const float* key_depth, FaceState fs, BinningState bs,
-                           uint2* ranges, hipStream_t st);
+// run: the sorted per-tile lists (renderer.cu:185-219): face_list ordered by (tile, depth key, emission order) + ranges.
+// key depth = depths or min_depths.  max_tile_entries (from the plan) picks the method: per-tile sorts in LDS, or -- lists
+// beyond TILE_SORT_MAX entries, or legacy = true -- the reference's way, one global stable radix sort.
+constexpr int64_t TILE_SORT_MAX = 32768;
+hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
+                           FaceState fs, BinningState bs, uint2* ranges, hipStream_t st);
 
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,

@@ -14,8 +14,9 @@
  *
  * The plan/run split replaces the reference's resize-callback lambdas
  * (render.cu:20-26, renderer.cu:174-183): the number of (tile,face) pairs is
- * data dependent, so `plan` bins the faces, returns the pair count, and the
- * caller sizes the binning scratch before `run`.
+ * data dependent, so `plan` bins the faces, returns the pair count (and the
+ * length of the longest tile list, which picks `run`'s sorting method), and
+ * the caller sizes the binning scratch before `run`.
  *
  * All pointers are DEVICE pointers to contiguous row-major arrays unless noted.
  * All functions enqueue on `stream` (a hipStream_t passed as void*; NULL = the
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DM2_ABI_VERSION 3
+#define DM2_ABI_VERSION 4
 #define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
 
 /* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
@@ -70,7 +71,8 @@ typedef struct dm2_render_desc {
                                     reference's as-written d(t)/d(verts) (auxiliary.h:272-280) */
 
 #define DM2_FLAG_LEGACY_KERNELS 2 /* composite kernels: per-pixel list walk (reference-shaped work distribution)
-                                    instead of the dense (pixel,face)-pair kernels; same results, kept for A/B */
+                                    instead of the dense (pixel,face)-pair kernels; tile lists: one global radix sort
+                                    instead of per-tile sorts; same results, kept for A/B */
 
 #define DM2_FLAG_NO_BACKWARD 4    /* forward only: no backward will follow (inference, torch.no_grad()): the forward skips the per-entry
                                     blend masks it otherwise leaves for dm2_backward (32 B per list entry).  A backward called
@@ -84,8 +86,9 @@ typedef struct dm2_render_desc {
 
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
-    DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 1 for Renderer (holds the packed face records, 256 B per
-                                 (view, face), that forward AND backward read), 0 for LayeredRenderer */
+    DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 2 * (B*tiles) + 1 for Renderer (holds the packed face records,
+                                 256 B per (view, face), that forward AND backward read), 2 * (B*tiles) for
+                                 LayeredRenderer; tiles = ceil(W/16) * ceil(H/16) */
     DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
     DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
     DM2_SCRATCH_LAYER_IMAGE = 3 /* count = B*H*W, aux = B*tiles    */
@@ -97,14 +100,19 @@ const char* dm2_last_error(void);
 /* Bytes of scratch of `kind` for `count` items (replaces required<T>(), state.h:63-69). */
 size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux);
 
-/* Bin faces into 16x16 tiles (preprocessFaceCUDA forward.cu:16-108 + InclusiveSum
- * renderer.cu:165-171) and return the number of (tile,face) pairs
- * (`num_rendered`, renderer.cu:174-179).  Synchronises `stream`. */
+/* Bin faces into 16x16 tiles (preprocessFaceCUDA forward.cu:16-108) and count the
+ * entries of every tile list; returns the number of (tile,face) pairs (`num_rendered`,
+ * the reference's InclusiveSum of tiles_touched, renderer.cu:165-179) and the length of
+ * the longest list (`max_tile_entries`, to be handed to dm2_forward_run).
+ * Synchronises `stream`. */
 int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
-                     void* stream, int64_t* num_rendered);
+                     void* stream, int64_t* num_rendered, int64_t* max_tile_entries);
 
-/* Key emit + (tile,depth) sort + tile ranges + per-pixel composite
- * (renderer.cu:185-266, FORWARD::renderCUDA forward.cu:139-432).
+/* Per-tile lists ordered by (depth key, emission order) + tile ranges + per-pixel composite
+ * (renderer.cu:185-266, FORWARD::renderCUDA forward.cu:139-432).  The lists are the ones the
+ * reference's global stable radix sort of (tile | depth) keys produces; they are built by
+ * bucketing the entries per tile and sorting every tile's segment on chip, unless
+ * max_tile_entries > 32768 or DM2_FLAG_LEGACY_KERNELS asks for the radix route.
  * out_color (B,H,W,3), out_depth (B,H,W): written for every pixel.
  * out_tri_cnt (B,H,W) int32: number of AA records the reference would hold
  * (min(#overlapping faces visited, K)); may be NULL.  The face / binning / image
@@ -112,7 +120,7 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
  * buffers the reference returns and takes back (render.cu:194, render.h:79-81).
  * The face scratch holds a packed copy of the per-face inputs as the forward saw
  * them; the backward differentiates with respect to those. */
-int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered,
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries,
                     void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes,
                     void* image_scratch, size_t image_bytes,
@@ -151,10 +159,10 @@ typedef struct dm2_layers_desc {
 } dm2_layers_desc;
 
 int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes,
-                    void* stream, int64_t* num_rendered);
+                    void* stream, int64_t* num_rendered, int64_t* max_tile_entries);
 /* render_layers (B,H,W,L) must be pre-filled with -1 and render_layers_cnt (B,H,W)
  * with 0 by the caller (render.cu:437-438). */
-int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered,
+int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries,
                    void* face_scratch, size_t face_bytes,
                    void* binning_scratch, size_t binning_bytes,
                    void* image_scratch, size_t image_bytes,

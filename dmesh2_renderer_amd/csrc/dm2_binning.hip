@@ -5,13 +5,16 @@
 // (tile | depth bits) keys.  Here the lists are bucketed first and sorted per tile:
 //
 //   plan  k_preprocess   forward.cu:16-108   one lane per (view,face): depth keys, cull, tile rect, packed record;
-//                                            one atomic per touched tile -> entries per tile
+//                                            one atomic per touched tile -> entries per tile, and (faces of up to
+//                                            four tiles) the entry's place in the tile's segment
 //         k_tile_scan                        exclusive scan of the tile counts: list starts, num_rendered (= the
 //                                            reference's scan of tiles_touched, renderer.cu:165-171), longest list
-//   run   k_bin_scatter  renderer.cu:415-465 (depth bits | face id) keys into the tile's segment, any order
-//         k_tile_sort                        one block per tile: bitonic sort of the segment in LDS (in global memory
-//                                            for a list beyond 2048 entries); the key is unique, and ascending
-//                                            (depth bits, face id) IS the stable radix order; writes face ids + ranges
+//   run   k_bin_scatter  renderer.cu:415-465 (depth bits | face id) keys into the tile's segment, any order (no
+//                                            atomics but for faces of more than four tiles)
+//         k_tile_sort                        one block per tile orders the segment: by counting (up to 512 entries), a
+//                                            bitonic network in LDS (2048) or in global memory (32768); the key is unique,
+//                                            and ascending (depth bits, face id) IS the stable radix order; writes face
+//                                            ids + ranges
 //
 // 1M faces / 1.6M entries at 1080p: 0.06 ms against 0.24 ms for emit + six radix passes + range detection.
 // Lists beyond TILE_SORT_MAX entries (a plan result) and DM2_FLAG_LEGACY_KERNELS take the reference's route:
@@ -66,11 +69,25 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
         }
     }
-    if (touched != 0) {                                                    // entries per tile (the lists' sizes)
+    if (touched != 0) {
+        // entries per tile (the lists' sizes).  A face with at most four tiles -- nearly all of a fine mesh -- takes its
+        // place inside each tile's segment right here (the atomic's return value) and keeps it for k_bin_scatter, which
+        // then needs no second round of atomics; larger faces are counted apart and placed behind them.
         const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
-        uint32_t* cnt = fs.tile_cnt + (int64_t)gx * gy * b;
-        for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = x0; x < x1; x++) atomicAdd(cnt + (y * gx + x), 1u);
+        const int64_t tb = (int64_t)gx * gy * b;
+        if (touched <= 4) {
+            const uint32_t w = x1 - x0;                                   // entry k (rect order): tile (x0 + k % w, y0 + k / w)
+            uint32_t rk[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {                                // (unrolled: four independent atomics in flight)
+                const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
+                rk[k] = k < touched ? atomicAdd(fs.tile_cnt + tb + ((y0 + ky) * gx + x0 + kx), 1u) : 0u;
+            }
+            fs.tile_rank[idx] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
+        } else {
+            for (uint32_t y = y0; y < y1; y++)
+                for (uint32_t x = x0; x < x1; x++) atomicAdd(fs.tile_cnt_big + tb + (y * gx + x), 1u);
+        }
     }
     fs.tiles_touched[idx] = touched;
     fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
@@ -88,14 +105,15 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
 
 // Exclusive scan of the tile counts (one block; thread i owns a run of consecutive tiles), their sum and maximum.
 __global__ void __launch_bounds__(1024)
-k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ start, uint32_t* __restrict__ meta) {
+k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, uint32_t* __restrict__ start,
+            uint32_t* __restrict__ meta) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t per = (Tn + 1023) / 1024, t0 = tid * per, t1 = t0 + per < Tn ? t0 + per : Tn;
     if (tid == 0) s_max = 0;
     uint32_t sum = 0, mx = 0;
-    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t]; sum += c; mx = mx > c ? mx : c; }
+    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t] + cnt_big[t]; sum += c; mx = mx > c ? mx : c; }
     const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
     if (lane == 63) s_w[wid] = inc;
     __syncthreads();
@@ -103,29 +121,42 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, uint32_t* __restrict__
     uint32_t before = 0, total = 0;
     for (int w = 0; w < 16; w++) { const uint32_t v = s_w[w]; if (w < wid) before += v; total += v; }
     uint32_t run = before + inc - sum;
-    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t]; start[t] = run; run += c; }
+    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t] + cnt_big[t]; start[t] = run; run += c; }
     __syncthreads();
     if (tid == 0) { meta[0] = total; meta[1] = s_max; }
 }
 
-// (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count); the position inside
-// the segment is whatever the atomic hands out -- k_tile_sort orders the segment.  ranges[t].y (zeroed) is the fill cursor.
+// (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count): entries of faces
+// with at most four tiles at the place the plan gave them, entries of larger faces behind those, wherever the cursor
+// (ranges[t].y, zeroed) puts them -- k_tile_sort orders the segment.
 __global__ void __launch_bounds__(256)
 k_bin_scatter(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ key_depth, FaceState fs,
               uint2* __restrict__ ranges, uint64_t* __restrict__ keys) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * F) return;
-    if (fs.tiles_touched[idx] == 0) return;
+    const uint32_t touched = fs.tiles_touched[idx];
+    if (touched == 0) return;
     const int b = (int)(idx / F), f = (int)(idx % F);
     const uint32_t lo = fs.rect_lo[idx], hi = fs.rect_hi[idx];
     const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
     const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
     const int64_t tile_base = (int64_t)gx * gy * b;
-    for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t x = x0; x < x1; x++) {
-            const int64_t t = tile_base + (y * gx + x);
-            keys[fs.tile_start[t] + atomicAdd(&ranges[t].y, 1u)] = key;
+    if (touched <= 4) {
+        const uint4 r4 = fs.tile_rank[idx];
+        const uint32_t rk[4] = {r4.x, r4.y, r4.z, r4.w};
+        const uint32_t w = x1 - x0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
+            if (k < touched) keys[fs.tile_start[tile_base + ((y0 + ky) * gx + x0 + kx)] + rk[k]] = key;
         }
+    } else {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                const int64_t t = tile_base + (y * gx + x);
+                keys[fs.tile_start[t] + fs.tile_cnt[t] + atomicAdd(&ranges[t].y, 1u)] = key;
+            }
+    }
 }
 
 // One block per tile: sort the tile's segment of (depth bits | face id) keys ascending, leave the face ids in face_list and
@@ -135,6 +166,7 @@ k_bin_scatter(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ 
 // of two long is padded with +inf -- real padding in LDS, virtual (skip exchanges whose upper index is past the end) in
 // global memory.
 constexpr int TILE_SORT_LDS = 2048;
+constexpr int TILE_SORT_RANK = 512;     // lists up to here are ordered by counting, longer ones by the network
 // pair p of a step: mirror step of a merge of size 2^lk (lk > 0), or half-cleaner at distance 2^lj (lk == 0)
 __device__ __forceinline__ void sort_pair_indices(int p, int lk, int lj, int& i, int& j) {
     if (lk) { const int blk = p >> (lk - 1), off = p & ((1 << (lk - 1)) - 1); i = (blk << lk) + off; j = (blk << lk) + ((1 << lk) - 1 - off); }
@@ -151,7 +183,7 @@ __device__ __forceinline__ void sort_step_sync(bool wave_local_next, bool wave_l
 __global__ void __launch_bounds__(256)
 k_tile_sort(int64_t Tn, uint32_t R, const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
             uint32_t* __restrict__ face_list, uint2* __restrict__ ranges, uint32_t* __restrict__ hit_valid) {
-    __shared__ uint64_t s_key[TILE_SORT_LDS];
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[TILE_SORT_LDS];
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x;
     const uint32_t s0 = tile_start[t], e0 = (t + 1 < Tn) ? tile_start[t + 1] : R;
@@ -163,7 +195,27 @@ k_tile_sort(int64_t Tn, uint32_t R, const uint32_t* __restrict__ tile_start, uin
     int LN = 0;
     while ((1 << LN) < n) LN++;
     const int N = 1 << LN, half = N >> 1;
-    if (n <= TILE_SORT_LDS) {
+    if (n <= TILE_SORT_RANK) {
+        // short list (the usual case): every key counts the keys below it -- they are all different, so that is its place.
+        // n broadcast reads (two keys each) and compares per thread, nothing waits for anything: cheaper than the network's
+        // ~LN^2 / 2 dependent LDS round trips up to a few hundred entries.
+        const int n2 = (n + 1) & ~1;
+        for (int i = tid; i < n2; i += 256) s_key[i] = i < n ? seg[i] : ~0ull;
+        __syncthreads();
+        const uint64_t k0 = tid < n ? s_key[tid] : 0ull, k1 = tid + 256 < n ? s_key[tid + 256] : 0ull;
+        int r0 = 0, r1 = 0;
+        const ulonglong2* const kk2 = reinterpret_cast<const ulonglong2*>(s_key);
+        if (n <= 256) {
+            for (int i = 0; i < (n2 >> 1); i++) { const ulonglong2 kk = kk2[i]; r0 += (int)(kk.x < k0) + (int)(kk.y < k0); }
+        } else {
+            for (int i = 0; i < (n2 >> 1); i++) {
+                const ulonglong2 kk = kk2[i];
+                r0 += (int)(kk.x < k0) + (int)(kk.y < k0); r1 += (int)(kk.x < k1) + (int)(kk.y < k1);
+            }
+        }
+        if (tid < n) face_list[s0 + r0] = (uint32_t)k0;
+        if (tid + 256 < n) face_list[s0 + r1] = (uint32_t)k1;
+    } else if (n <= TILE_SORT_LDS) {
         for (int i = tid; i < N; i += 256) s_key[i] = i < n ? seg[i] : ~0ull;
         __syncthreads();
         for (int lk = 1; lk <= LN; lk++) {
@@ -274,14 +326,14 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     StageTimer tm(ST_PREP, st);
     hipError_t e = hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
     if (e != hipSuccess || Tn == 0) return e;
-    e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)Tn * sizeof(uint32_t), st);
+    e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)(2 * Tn) * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (pack && fs.recs)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_start, fs.plan_meta);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta);
     return hipSuccess;
 }
 

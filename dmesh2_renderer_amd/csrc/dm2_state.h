@@ -46,9 +46,11 @@ struct FaceState {
     void* scan_temp; size_t scan_temp_bytes;
     uint4* recs;              // (BF, FACE_REC_U4) packed face records; nullptr when the caller needs none (layers)
     // tile-bucketed binning (dm2_binning.hip): filled by the plan step, consumed by the run step
-    uint32_t* tile_cnt;       // (Tn)  list entries per tile
-    uint32_t* tile_start;     // (Tn)  exclusive scan of tile_cnt
+    uint32_t* tile_cnt;       // (Tn)  list entries per tile from faces that touch at most four tiles (they keep their place, below)
+    uint32_t* tile_cnt_big;   // (Tn)  list entries per tile from faces that touch more
+    uint32_t* tile_start;     // (Tn)  exclusive scan of tile_cnt + tile_cnt_big
     uint32_t* plan_meta;      // [0] num_rendered  [1] entries of the longest tile list
+    uint4* tile_rank;         // (BF)  faces with 1..4 tiles: the entry's place among the tile's small-face entries, rect order
     static FaceState carve(void* base, int64_t BF, int64_t Tn, size_t scan_temp_bytes, bool with_recs, size_t* total = nullptr) {
         Carver c(base); FaceState s;
         s.depths = c.take<float>(BF); s.min_depths = c.take<float>(BF); s.max_depths = c.take<float>(BF);
@@ -56,7 +58,9 @@ struct FaceState {
         s.rect_lo = c.take<uint32_t>(BF); s.rect_hi = c.take<uint32_t>(BF);
         s.scan_temp = c.take<char>(scan_temp_bytes); s.scan_temp_bytes = scan_temp_bytes;
         s.recs = with_recs ? c.take<uint4>(BF * FACE_REC_U4) : nullptr;
-        s.tile_cnt = c.take<uint32_t>(Tn); s.tile_start = c.take<uint32_t>(Tn); s.plan_meta = c.take<uint32_t>(4);
+        s.tile_cnt = c.take<uint32_t>(2 * Tn); s.tile_cnt_big = s.tile_cnt + Tn;      // (one memset clears both)
+        s.tile_start = c.take<uint32_t>(Tn); s.plan_meta = c.take<uint32_t>(4);
+        s.tile_rank = c.take<uint4>(Tn > 0 ? BF : 0);
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }

@@ -1,6 +1,6 @@
 """Tile lists of the HIP path against the oracle's binning (reference: renderer.cu:165-219, one global stable radix
 sort of (tile | depth bits) keys): every route of dm2_binning.hip must leave the same face_list and ranges --
-per-tile sorts in LDS (lists up to 2048 entries), per-tile sorts in global memory (up to 32768), the radix route
+per-tile sorts in LDS (by counting up to 512 entries, a bitonic network up to 2048), per-tile sorts in global memory (up to 32768), the radix route
 (longer lists, DM2_FLAG_LEGACY_KERNELS) -- including the order of entries with EQUAL depth keys (emission order =
 face id ascending), which only a stable sort or a (depth, face id) key reproduces."""
 import numpy as np
@@ -50,7 +50,8 @@ def _scene(W, H, F, seed, dc, cams=1, dup=False):
 
 CASES = {
     # name: (W, H, F, depth complexity, cameras, duplicated faces, expected longest list at least)
-    "lds_lists": (96, 80, 4000, 6.0, 2, False, 1),
+    "short_lists": (96, 80, 4000, 6.0, 2, False, 1),               # ordered by counting (<= 512 entries)
+    "lds_network": (64, 48, 6000, 60.0, 1, False, 513),             # bitonic network in LDS (513 .. 2048)
     "ties": (64, 64, 700, 8.0, 1, True, 1),
     "one_tile_global_sort": (16, 16, 3000, 3000.0, 1, False, 2049),
     "mixed_lds_global": (48, 32, 9000, 2500.0, 1, False, 2049),

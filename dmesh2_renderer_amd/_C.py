@@ -89,7 +89,7 @@ EXPORTS = {
     "dm2_debug_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]),
 }
 
-STAGE_NAMES = ["preprocess_scan", "emit_keys", "radix_sort", "tile_ranges", "forward_composite", "backward_composite"]
+STAGE_NAMES = ["preprocess_scan", "bin_scatter", "tile_sort", "tile_ranges", "forward_composite", "backward_composite"]
 
 
 def profile_enable(on: bool):

@@ -35,19 +35,26 @@ int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-struct PinnedWord {     // per-thread pinned staging word for the num_rendered read-back
+struct PinnedWord {     // per-thread pinned staging words + event for the plan's read-back
     uint32_t* p = nullptr;
-    ~PinnedWord() { if (p) (void)hipHostFree(p); }
+    hipEvent_t ev = nullptr;
+    ~PinnedWord() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
 };
 thread_local PinnedWord g_pin;
 
-// (num_rendered, entries of the longest tile list) of the plan that just ran on `st`: the one host read-back of a forward
-int read_plan_meta(const uint32_t* plan_meta, hipStream_t st, int64_t* num_rendered, int64_t* max_tile_entries) {
+// (num_rendered, entries of the longest tile list) of the plan that just ran on `st`: the one host read-back of a forward.
+// Two halves (an event, not a stream synchronise: work a caller enqueues on the stream afterwards is not waited for).
+int plan_meta_enqueue(const uint32_t* plan_meta, hipStream_t st) {
     if (!g_pin.p) DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocDefault));
+    if (!g_pin.ev) DM2_HIP(hipEventCreateWithFlags(&g_pin.ev, hipEventDisableTiming));
     DM2_HIP(hipMemcpyAsync(g_pin.p, plan_meta, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    DM2_HIP(hipStreamSynchronize(st));
+    DM2_HIP(hipEventRecord(g_pin.ev, st));
+    return 0;
+}
+int plan_meta_wait(int64_t* num_rendered, int64_t* max_tile_entries) {
+    DM2_HIP(hipEventSynchronize(g_pin.ev));
     *num_rendered = (int64_t)g_pin.p[0];
-    if (max_tile_entries) *max_tile_entries = (int64_t)g_pin.p[1];
+    *max_tile_entries = (int64_t)g_pin.p[1];
     return 0;
 }
 
@@ -159,7 +166,8 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
     dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d, st));
     DM2_HIP(hipGetLastError());
-    return read_plan_meta(fs.plan_meta, st, num_rendered, max_tile_entries);
+    if (plan_meta_enqueue(fs.plan_meta, st)) return 1;
+    return plan_meta_wait(num_rendered, max_tile_entries);
 }
 
 int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
@@ -236,7 +244,8 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     // patch_min = 0 (renderer.cu:557-558): a null patch_min means "all zeros"
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr, st));
     DM2_HIP(hipGetLastError());
-    return read_plan_meta(fs.plan_meta, st, num_rendered, max_tile_entries);
+    if (plan_meta_enqueue(fs.plan_meta, st)) return 1;
+    return plan_meta_wait(num_rendered, max_tile_entries);
 }
 
 int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,

@@ -39,6 +39,9 @@ namespace dm2 {
 constexpr int BM_CAND = 32;      // candidate entries per chunk: two per 16-lane group of the cooperative record copy
 static_assert(BM_CAND * 4 <= TILE_PIX && 2 * BM_CAND <= 64, "one scan thread per (face, wave); one id window per wave");
 constexpr int BM_SLOTS = BM_CAND * 4;
+#ifndef DM2_BM_CARRY
+#define DM2_BM_CARRY 2         // phase D takes ray, corners, colours, NDC z of its pair from phase B2 in registers (0: re-reads LDS; A/B at cfg4: -3.7 %)
+#endif
 #ifndef DM2_BM_ACC
 #define DM2_BM_ACC 33       // odd pitch: the emit lanes of different faces add to different LDS banks (A/B at cfg4: 32 -> 33, -0.4 %)
 #endif
@@ -244,6 +247,13 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         float i0 = 0.f, i1 = 0.f, i2 = 0.f, ratio = 0.f, alpha = 0.f;
         int code = 0;
         bool blend = false;
+#if DM2_BM_CARRY
+        // carried from B2 into phase D in registers (phase C in between needs few): ray, world corners, colours, NDC z
+        f3 k_ro = {0, 0, 0}, k_rd = {0, 0, 0}, k_p0 = {0, 0, 0}, k_p1 = {0, 0, 0}, k_p2 = {0, 0, 0};
+#if DM2_BM_CARRY > 1
+        float k_col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, k_dep[3] = {0, 0, 0}, k_int = 0.f, k_opa = 0.f;
+#endif
+#endif
         if (have) {
             const int lo = (int)(mk >> 9) - 1;                                    // the slot of pair tid, first pair mk & 511
             j = lo >> 2;
@@ -264,6 +274,14 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
             const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
             f3 tuv = {0, 0, 0};
+#if DM2_BM_CARRY
+            k_ro = ro; k_rd = rd; k_p0 = p0; k_p1 = p1; k_p2 = p2;
+#if DM2_BM_CARRY > 1
+#pragma unroll
+            for (int c = 0; c < 9; c++) k_col[c] = fc.col[c];
+            k_dep[0] = fc.dep[0]; k_dep[1] = fc.dep[1]; k_dep[2] = fc.dep[2]; k_int = fc.intense; k_opa = fc.opacity;
+#endif
+#endif
             if (ray_tri_intersection(ro, rd, p0, p1, p2, tuv)) {
                 float iuc, ivc;
                 clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
@@ -365,7 +383,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             seg_scan16(nact, s1, s2, s4, s8);
             const bool emit = ((l16 == 15) | (kn != jkey)) & (jkey >= 0) & (nact > 0.f);
             float* const arow = acc + j * BM_ACC;
+#if DM2_BM_CARRY < 2
             const FaceRec& fcD = recs[j];
+#endif
             float dL_diu = 0.f, dL_div = 0.f, dL_doarea = 0.f;
             {   // group 1: vertex colours, NDC depth, intensity, opacity
                 float g1[14];
@@ -374,7 +394,13 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 if (active) {
                     const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
                     const float qc0 = pr.c0, qc1 = pr.c1, qc2 = pr.c2, qd = pr.depth;   // dL/dcolour, dL/ddepth of the pixel
+#if DM2_BM_CARRY > 1
+                    const float intense = k_int, opacity = k_opa;
+                    const float* const colD = k_col; const float* const depD = k_dep;
+#else
                     const float intense = fcD.intense, opacity = fcD.opacity;
+                    const float* const colD = fcD.col; const float* const depD = fcD.dep;
+#endif
                     const float dics[3] = {qc0 * alpha * Tq, qc1 * alpha * Tq, qc2 * alpha * Tq};
                     const float did = qd * alpha * Tq;
                     g1[12] = dL_dalpha * ratio;
@@ -383,16 +409,16 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     float dL_di0 = 0.f, dL_di1 = 0.f, dL_di2 = 0.f, dL_dfint = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        dL_di0 += fcD.col[ch] * dics[ch] * intense;
-                        dL_di1 += fcD.col[3 + ch] * dics[ch] * intense;
-                        dL_di2 += fcD.col[6 + ch] * dics[ch] * intense;
+                        dL_di0 += colD[ch] * dics[ch] * intense;
+                        dL_di1 += colD[3 + ch] * dics[ch] * intense;
+                        dL_di2 += colD[6 + ch] * dics[ch] * intense;
                         g1[ch] = 0.f + i0 * dics[ch] * intense;
                         g1[3 + ch] = 0.f + i1 * dics[ch] * intense;
                         g1[6 + ch] = 0.f + i2 * dics[ch] * intense;
-                        dL_dfint += (i0 * fcD.col[ch] + i1 * fcD.col[3 + ch] + i2 * fcD.col[6 + ch]) * dics[ch];
+                        dL_dfint += (i0 * colD[ch] + i1 * colD[3 + ch] + i2 * colD[6 + ch]) * dics[ch];
                     }
                     g1[13] = dL_dfint;
-                    dL_di0 += fcD.dep[0] * did; dL_di1 += fcD.dep[1] * did; dL_di2 += fcD.dep[2] * did;
+                    dL_di0 += depD[0] * did; dL_di1 += depD[1] * did; dL_di2 += depD[2] * did;
                     g1[9] = 0.f + i0 * did; g1[10] = 0.f + i1 * did; g1[11] = 0.f + i2 * did;
                     float diuc_diu, diuc_div, divc_diu, divc_div;
                     clamp_bary_uv_grad(code, diuc_diu, diuc_div, divc_diu, divc_div);
@@ -426,9 +452,13 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 #pragma unroll
                 for (int c = 0; c < 9; c++) g3[c] = 0.f;
                 if (active) {
+#if DM2_BM_CARRY
+                    const f3 ro = k_ro, rd = k_rd, p0 = k_p0, p1 = k_p1, p2 = k_p2;
+#else
                     const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
                     const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
                     const f3 p0 = {fcD.v[0], fcD.v[1], fcD.v[2]}, p1 = {fcD.v[3], fcD.v[4], fcD.v[5]}, p2 = {fcD.v[6], fcD.v[7], fcD.v[8]};
+#endif
                     f3 du0, du1, du2, dv0, dv1, dv2;
                     ray_tri_intersection_grad(ro, rd, p0, p1, p2, corrected, du0, du1, du2, dv0, dv1, dv2);
                     const f3 dp0 = dL_diu * du0 + dL_div * dv0;

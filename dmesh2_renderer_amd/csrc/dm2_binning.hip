@@ -35,7 +35,9 @@
 namespace dm2 {
 
 // PACK: also write the face's packed record (dm2_stage.h) for the composite kernels -- only for faces that reach a
-// tile list.  `d` is read only then.
+// tile list.  `d` is read only then.  (A/B at cfg4: packing in a kernel of its own behind the plan's read-back, so that
+// it runs while the host sizes and enqueues the run step, costs more than it hides -- the binning part alone is bound by
+// its atomics, 0.08 ms, which here disappear behind the record traffic: 0.16 ms fused against 0.08 + 0.13 ms split.)
 template <bool PACK>
 __global__ void __launch_bounds__(256)
 k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __restrict__ patch_min,
@@ -103,27 +105,52 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     }
 }
 
-// Exclusive scan of the tile counts (one block; thread i owns a run of consecutive tiles), their sum and maximum.
+// Exclusive scan of the tile counts, their sum and maximum.  One block; 8192 tiles (a 1080p frame) per round: coalesced
+// loads into LDS, thread i scans the run of 8 consecutive counts [8i, 8i + 8) there, coalesced stores.  (A thread that
+// reads its run straight from global memory touches 32 cache lines per wave instruction -- 14 us on the one CU this
+// kernel runs on, against 4.)
 __global__ void __launch_bounds__(1024)
 k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, uint32_t* __restrict__ start,
             uint32_t* __restrict__ meta) {
+    constexpr int RUN = 8, ROUND = 1024 * RUN;
+    __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t per = (Tn + 1023) / 1024, t0 = tid * per, t1 = t0 + per < Tn ? t0 + per : Tn;
     if (tid == 0) s_max = 0;
-    uint32_t sum = 0, mx = 0;
-    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t] + cnt_big[t]; sum += c; mx = mx > c ? mx : c; }
-    const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
-    if (lane == 63) s_w[wid] = inc;
-    __syncthreads();
+    uint32_t carry = 0, mx = 0;
+    for (int64_t base = 0; base < Tn; base += ROUND) {
+#pragma unroll
+        for (int k = 0; k < RUN; k++) {
+            const int i = k * 1024 + tid;
+            const int64_t t = base + i;
+            s_c[i + (i >> 5)] = t < Tn ? cnt[t] + cnt_big[t] : 0u;
+        }
+        __syncthreads();
+        uint32_t c8[RUN], sum = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { const int i = tid * RUN + k; c8[k] = s_c[i + (i >> 5)]; sum += c8[k]; mx = mx > c8[k] ? mx : c8[k]; }
+        const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
+        if (lane == 63) s_w[wid] = inc;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t v = s_w[w]; if (w < wid) before += v; total += v; }
+        uint32_t run = carry + before + inc - sum;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) { const int i = tid * RUN + k; s_c[i + (i >> 5)] = run; run += c8[k]; }
+        carry += total;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RUN; k++) {
+            const int i = k * 1024 + tid;
+            const int64_t t = base + i;
+            if (t < Tn) start[t] = s_c[i + (i >> 5)];
+        }
+        __syncthreads();                                   // s_c and s_w are rewritten by the next round
+    }
     if (mx) atomicMax(&s_max, mx);
-    uint32_t before = 0, total = 0;
-    for (int w = 0; w < 16; w++) { const uint32_t v = s_w[w]; if (w < wid) before += v; total += v; }
-    uint32_t run = before + inc - sum;
-    for (int64_t t = t0; t < t1; t++) { const uint32_t c = cnt[t] + cnt_big[t]; start[t] = run; run += c; }
     __syncthreads();
-    if (tid == 0) { meta[0] = total; meta[1] = s_max; }
+    if (tid == 0) { meta[0] = carry; meta[1] = s_max; }
 }
 
 // (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count): entries of faces
@@ -324,9 +351,8 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     const int64_t Tn = (int64_t)B * gx * gy;
     const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
-    hipError_t e = hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
-    if (e != hipSuccess || Tn == 0) return e;
-    e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)(2 * Tn) * sizeof(uint32_t), st);
+    if (Tn == 0) return hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)(2 * Tn) * sizeof(uint32_t), st);   // (k_tile_scan writes plan_meta)
     if (e != hipSuccess) return e;
     if (pack && fs.recs)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);

@@ -20,7 +20,7 @@
  *
  * All pointers are DEVICE pointers to contiguous row-major arrays unless noted.
  * All functions enqueue on `stream` (a hipStream_t passed as void*; NULL = the
- * null stream); only the plan functions synchronise it (one 8-byte D2H read).
+ * null stream); only the plan functions wait for the GPU (for one 8-byte D2H read).
  * Return value: 0 on success, non-zero on error with a message available from
  * dm2_last_error() (thread local).  The library keeps no global state besides
  * a per-thread pinned staging word.
@@ -104,7 +104,7 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux);
  * entries of every tile list; returns the number of (tile,face) pairs (`num_rendered`,
  * the reference's InclusiveSum of tiles_touched, renderer.cu:165-179) and the length of
  * the longest list (`max_tile_entries`, to be handed to dm2_forward_run).
- * Synchronises `stream`. */
+ * Waits for the 8-byte read-back of those two numbers. */
 int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
                      void* stream, int64_t* num_rendered, int64_t* max_tile_entries);
 
@@ -225,7 +225,8 @@ int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, con
  * forward/backward/layers entry points record hipEvents on `stream` around every stage of
  * the calling thread's next calls; dm2_profile_read waits for the last one and returns the
  * milliseconds of each stage of the most recent forward_plan/forward_run/backward call:
- * [0] preprocess+scan  [1] key emit  [2] radix sort  [3] tile ranges
+ * [0] preprocess + tile scan  [1] scatter into the tile segments (radix route: scan + key emit)
+ * [2] per-tile sorts (radix route: the radix sort)  [3] tile ranges (radix route only)
  * [4] forward composite [5] backward composite.  Returns the number of values written. */
 #define DM2_PROFILE_STAGES 6
 void dm2_profile_enable(int on);

@@ -34,6 +34,42 @@
 
 namespace dm2 {
 
+// One count per active lane into cnt[STRIDE * t].  RANK: also returns a place per lane, as its own atomicAdd(.., 1) would.
+// A global atomic costs the same ~60 ps per LANE whether or not lanes collide (1.6 M of them: 0.08 ms), so lanes of a wave
+// that hit the same tile -- neighbouring faces of a mesh, a tet lattice -- are grouped first: the group's first lane adds the
+// group's size, the others take the consecutive places.  Grouping costs a few scalar instructions per distinct tile; a
+// probe skips it where hardly any lanes share (a triangle soup).  Call with the whole wave (act = lane has a tile).
+template <bool RANK, int STRIDE>
+__device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, bool act) {
+    const unsigned long long all = __ballot(act);
+    if (all == 0) return 0u;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int l0 = __ffsll((long long)all) - 1;
+    const unsigned long long m0 = __ballot(act && t == (uint32_t)__builtin_amdgcn_readlane((int)t, l0));
+    if (__popcll(m0) * 8 <= __popcll(all)) {
+        uint32_t r = 0;
+        if (act) { if (RANK) r = atomicAdd(cnt + (int64_t)STRIDE * t, 1u); else atomicAdd(cnt + (int64_t)STRIDE * t, 1u); }
+        return r;
+    }
+    unsigned long long todo = all, mine = 0;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, l);
+        const unsigned long long m = __ballot(act && t == tl);
+        if (act && t == tl) mine = m;
+        todo &= ~m;
+    }
+    const int leader = act ? __ffsll((long long)mine) - 1 : lane;
+    uint32_t base = 0;
+    if (act && lane == leader) {
+        if (RANK) base = atomicAdd(cnt + (int64_t)STRIDE * t, (uint32_t)__popcll(mine));
+        else atomicAdd(cnt + (int64_t)STRIDE * t, (uint32_t)__popcll(mine));
+    }
+    if (!RANK) return 0u;
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+}
+
 // PACK: also write the face's packed record (dm2_stage.h) for the composite kernels -- only for faces that reach a
 // tile list.  `d` is read only then.  (A/B at cfg4: packing in a kernel of its own behind the plan's read-back, so that
 // it runs while the host sizes and enqueues the run step, costs more than it hides -- the binning part alone is bound by
@@ -71,24 +107,33 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
         }
     }
-    if (touched != 0) {
+    {
         // entries per tile (the lists' sizes).  A face with at most four tiles -- nearly all of a fine mesh -- takes its
         // place inside each tile's segment right here (the atomic's return value) and keeps it for k_bin_scatter, which
         // then needs no second round of atomics; larger faces are counted apart and placed behind them.
-        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
-        const int64_t tb = (int64_t)gx * gy * b;
-        if (touched <= 4) {
-            const uint32_t w = x1 - x0;                                   // entry k (rect order): tile (x0 + k % w, y0 + k / w)
+        // (wave-uniform control flow from here to the end of the block: wave_count_tiles is a wave-wide operation)
+        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
+        const uint32_t tb = (uint32_t)((int64_t)gx * gy * b);
+        const bool small = touched != 0 && touched <= 4, big = touched > 4;
+        if (__ballot(small)) {
+            const uint32_t w = x1 - x0;                                       // entry k (rect order): tile (x0 + k % w, y0 + k / w)
             uint32_t rk[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {                                // (unrolled: four independent atomics in flight)
+            for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
-                rk[k] = k < touched ? atomicAdd(fs.tile_cnt + tb + ((y0 + ky) * gx + x0 + kx), 1u) : 0u;
+                const bool act = small && k < touched;
+                rk[k] = wave_count_tiles<true, 1>(fs.tile_cnt, act ? tb + ((y0 + ky) * gx + x0 + kx) : 0u, act);
             }
-            fs.tile_rank[idx] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
-        } else {
-            for (uint32_t y = y0; y < y1; y++)
-                for (uint32_t x = x0; x < x1; x++) atomicAdd(fs.tile_cnt_big + tb + (y * gx + x), 1u);
+            if (small) fs.tile_rank[idx] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
+        }
+        if (__ballot(big)) {
+            uint32_t cx = x0, cy = y0;
+            for (uint32_t k = 0; ; k++) {
+                const bool act = big && k < touched;
+                if (!__ballot(act)) break;
+                wave_count_tiles<false, 1>(fs.tile_cnt_big, act ? tb + (cy * gx + cx) : 0u, act);
+                if (++cx == x1) { cx = x0; cy++; }
+            }
         }
     }
     fs.tiles_touched[idx] = touched;
@@ -159,16 +204,17 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
 __global__ void __launch_bounds__(256)
 k_bin_scatter(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ key_depth, FaceState fs,
               uint2* __restrict__ ranges, uint64_t* __restrict__ keys) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * F) return;
-    const uint32_t touched = fs.tiles_touched[idx];
-    if (touched == 0) return;
+    const int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = idx0 < (int64_t)B * F;
+    const int64_t idx = valid ? idx0 : 0;
+    const uint32_t touched = valid ? fs.tiles_touched[idx] : 0u;
+    if (!__ballot(touched != 0)) return;
     const int b = (int)(idx / F), f = (int)(idx % F);
     const uint32_t lo = fs.rect_lo[idx], hi = fs.rect_hi[idx];
-    const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
+    const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
     const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
     const int64_t tile_base = (int64_t)gx * gy * b;
-    if (touched <= 4) {
+    if (touched != 0 && touched <= 4) {
         const uint4 r4 = fs.tile_rank[idx];
         const uint32_t rk[4] = {r4.x, r4.y, r4.z, r4.w};
         const uint32_t w = x1 - x0;
@@ -177,12 +223,18 @@ k_bin_scatter(int B, int F, uint32_t gx, uint32_t gy, const float* __restrict__ 
             const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
             if (k < touched) keys[fs.tile_start[tile_base + ((y0 + ky) * gx + x0 + kx)] + rk[k]] = key;
         }
-    } else {
-        for (uint32_t y = y0; y < y1; y++)
-            for (uint32_t x = x0; x < x1; x++) {
-                const int64_t t = tile_base + (y * gx + x);
-                keys[fs.tile_start[t] + fs.tile_cnt[t] + atomicAdd(&ranges[t].y, 1u)] = key;
-            }
+    }
+    const bool big = touched > 4;                 // (0 for the lanes past the end: they stay in the wave for the ballots)
+    if (__ballot(big)) {
+        uint32_t cx = x0, cy = y0;
+        for (uint32_t k = 0; ; k++) {
+            const bool act = big && k < touched;
+            if (!__ballot(act)) break;
+            const uint32_t t = act ? (uint32_t)tile_base + (cy * gx + cx) : 0u;
+            const uint32_t place = wave_count_tiles<true, 2>(&ranges[0].y, t, act);
+            if (act) keys[fs.tile_start[t] + fs.tile_cnt[t] + place] = key;
+            if (++cx == x1) { cx = x0; cy++; }
+        }
     }
 }
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_traffic.json from the per-kernel PMC summaries tools/profile_run.sh leaves
+(<tag>_cfg4_hbm_traffic.txt, <tag>_cfg4_sq_counters.txt).  usage: make_traffic_json.py <dir> <tag> > out.json"""
+import json
+import re
+import sys
+
+d, tag = sys.argv[1], sys.argv[2]
+
+
+def parse(path):
+    out, kern = {}, None
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        m = re.match(r"\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+\-]+)", line)
+        if m and kern:
+            out.setdefault(kern, {})[m.group(1)] = float(m.group(2))
+        elif not line.startswith(" "):
+            kern = line.strip()
+    return out
+
+
+hbm = parse(f"{d}/{tag}_cfg4_hbm_traffic.txt")
+sq = parse(f"{d}/{tag}_cfg4_sq_counters.txt")
+res = {
+    "config": "cfg4",
+    "source": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_* in separate passes of `python3 bench.py --steps 3 --warmup 1 "
+              f"--no-cpu` (tools/profile_run.sh); means per launch; profiles/{tag}_cfg4_hbm_traffic.txt, {tag}_cfg4_sq_counters.txt",
+    "note_units": "FETCH_SIZE / WRITE_SIZE are reported in KiB.  gfx950 tallies a 128-B read request as 64 B for wide coalesced reads "
+                  "(MI355X_MICROARCH.md, HBM): hbm_bytes_corrected = 2 x FETCH + WRITE is the figure to compare with a byte count; "
+                  "hbm_bytes_raw keeps the counters as they are.  The records (16 B per lane, LDS-direct) and rays make up most of the "
+                  "reads, so the correction applies to them; it over-corrects the 4-byte gathers.",
+}
+for k, v in hbm.items():
+    name = k.replace("void ", "").replace("dm2::", "").split("<")[0]
+    if not name or "FETCH_SIZE" not in v:
+        continue
+    f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+    e = {"fetch_kb": round(f), "write_kb": round(w), "hbm_bytes_raw": int((f + w) * 1024), "hbm_bytes_corrected": int((2 * f + w) * 1024)}
+    if k in sq and "SQ_INSTS_VALU" in sq[k]:
+        e["sq_insts_valu"] = sq[k]["SQ_INSTS_VALU"]
+    res[name] = e
+print(json.dumps(res, indent=1))

@@ -27,6 +27,10 @@ namespace dm2 { unsigned long long* stamps_table(); }   // device pointer to [2]
 #define STAMP_PARAM
 #define STAMP_ARG(which)
 #define STAMP_DECL
+#ifdef DM2_ISA_MARKS    // static budget builds (tools/isa_budget.py): a comment line in the -save-temps ISA at every stamp point
+#define STAMP(i) asm volatile("; DM2_MARK after_stamp_" #i);
+#else
 #define STAMP(i)
+#endif
 #define STAMP_FLUSH
 #endif

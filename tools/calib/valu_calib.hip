@@ -88,12 +88,71 @@ template <int KIND> static void sweep(float* d_out, unsigned long long* d_cyc, i
     for (int w : {1, 2, 4}) run<KIND, 1>(w, d_out, d_cyc, ncu);
 }
 
-int main() {
+
+// packed fp32 (two fp32 operations per lane and instruction: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on 64-bit register pairs)
+typedef float v2f __attribute__((ext_vector_type(2)));
+enum PkKind { PK_MUL = 0, PK_ADD = 1, PK_FMA = 2, PK_NKIND = 3 };
+static const char* pk_name[PK_NKIND] = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"};
+template <int KIND, int NCHAIN>
+__global__ void __launch_bounds__(64) k_calib_pk(float* out, unsigned long long* cyc, float seed) {
+    v2f a[NCHAIN];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) a[c] = v2f{seed + (float)(threadIdx.x + c), seed - (float)c};
+    const v2f m = {seed * 0.999f, seed * 0.998f}, b = {seed * 0.001f, seed * 0.002f};
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNROLL / NCHAIN; u++) {
+#pragma unroll
+            for (int c = 0; c < NCHAIN; c++) {
+                v2f& x = a[c];
+                if (KIND == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(m));
+                else if (KIND == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+                else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(m), "v"(b));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHAIN; c++) s += a[c].x + a[c].y;
+    if (s == 123.456f) out[0] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int KIND, int NCHAIN>
+static void run_pk(int waves_per_simd, float* d_out, unsigned long long* d_cyc, int ncu) {
+    const int blocks = ncu * 4 * waves_per_simd;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_calib_pk<KIND, NCHAIN>), dim3(blocks), dim3(64), 0, 0, d_out, d_cyc, 1.0f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_calib_pk<KIND, NCHAIN>), dim3(blocks), dim3(64), 0, 0, d_out, d_cyc, 1.0f);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> cyc(blocks);
+    CK(hipMemcpy(cyc.data(), d_cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean = 0; for (auto c : cyc) mean += (double)c; mean /= blocks;
+    const double instr = (double)ITER * UNROLL;
+    printf("{\"kind\": \"%s (2 fp32 ops per lane)\", \"chains\": %d, \"waves_per_simd\": %d, \"cycles_per_instr_seen_by_wave\": %.3f, \"cycles_per_instr_per_simd\": %.3f, "
+           "\"wall_ms\": %.4f, \"wall_ginstr_per_s_per_simd\": %.3f}\n",
+           pk_name[KIND], NCHAIN, waves_per_simd, mean / instr, mean / instr / waves_per_simd, ms, instr * waves_per_simd / (ms * 1e-3) / 1e9);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+template <int KIND> static void sweep_pk(float* d_out, unsigned long long* d_cyc, int ncu) {
+    for (int w : {1, 2, 4, 8}) run_pk<KIND, 8>(w, d_out, d_cyc, ncu);
+    for (int w : {1, 2, 4}) run_pk<KIND, 1>(w, d_out, d_cyc, ncu);
+}
+
+int main(int argc, char** argv) {
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int ncu = p.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d}\n", p.gcnArchName, ncu, p.clockRate);
     float* d_out; unsigned long long* d_cyc;
     CK(hipMalloc(&d_out, 4096)); CK(hipMalloc(&d_cyc, sizeof(unsigned long long) * ncu * 4 * 8));
+    sweep_pk<PK_MUL>(d_out, d_cyc, ncu);
+    sweep_pk<PK_ADD>(d_out, d_cyc, ncu);
+    sweep_pk<PK_FMA>(d_out, d_cyc, ncu);
+    if (argc > 1) return 0;                               // any argument: the packed kinds only
     sweep<K_FMA>(d_out, d_cyc, ncu);
     sweep<K_ADD>(d_out, d_cyc, ncu);
     sweep<K_CNDMASK>(d_out, d_cyc, ncu);

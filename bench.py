@@ -307,12 +307,15 @@ def main():
     dLd_b = dLd[:, op.y0:op.y0 + op.rows].contiguous()
 
     # N > 1, what crosses the links (DM2_BENCH_REDUCE):
-    #   "sparse" (default)  leaf gradients, touched rows only: all-to-all to the row owners + all-gather of the reduced slices
-    #   "leaves"            leaf gradients, ONE dense all-reduce of 24P + 4F + 4BF bytes (80 MB at cfg4)
+    #   "leaves" (default)  leaf gradients, ONE dense all-reduce of 24P + 4F + 4BF bytes (80 MB at cfg4) on the backward's own
+    #                       packed buffer: no local packing at all
+    #   "sparse"            leaf gradients, touched rows only: all-to-all to the row owners + all-gather of the reduced slices.
+    #                       Fewer bytes per link, but its device-side packing costs 0.4-0.6 ms per step and rank
+    #                       (tools/exchange_time.py on one MI355X) -- more than the bytes it saves at 2..8 GPUs of one node
     #   "op6"               the op's six gradient tensors, one dense all-reduce (140 MB; SURVEY 8(e) as written)
     # All three leave every rank with the full gradients; "sparse"/"leaves" push this rank's dverts_ndc / daa_face_verts
     # partials through the fused host-prep backward locally first (sharding.BandShardedOp.backward_leaves).
-    reduce_mode = os.environ.get("DM2_BENCH_REDUCE", "sparse")
+    reduce_mode = os.environ.get("DM2_BENCH_REDUCE", "leaves")
     if backend != "nccl" and reduce_mode == "sparse" and world > 1 and device.type == "cuda":
         reduce_mode = "leaves"                             # gloo has no all-to-all on device tensors
     sc = _LAST["scene"]

@@ -55,6 +55,7 @@ int plan_meta_wait(int64_t* num_rendered, int64_t* max_tile_entries) {
     DM2_HIP(hipEventSynchronize(g_pin.ev));
     *num_rendered = (int64_t)g_pin.p[0];
     *max_tile_entries = (int64_t)g_pin.p[1];
+    if (g_pin.p[1] == 0xFFFFFFFFu) { *num_rendered = 0; *max_tile_entries = 0; return fail("more than 2^31 - 1 (tile, face) pairs: render smaller patches"); }
     return 0;
 }
 

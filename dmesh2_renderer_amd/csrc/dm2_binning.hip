@@ -164,6 +164,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) s_max = 0;
     uint32_t carry = 0, mx = 0;
+    unsigned long long carry64 = 0;                       // the list positions are 32-bit (as the reference's int num_rendered): notice a wrap
     for (int64_t base = 0; base < Tn; base += ROUND) {
 #pragma unroll
         for (int k = 0; k < RUN; k++) {
@@ -183,7 +184,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
         uint32_t run = carry + before + inc - sum;
 #pragma unroll
         for (int k = 0; k < RUN; k++) { const int i = tid * RUN + k; s_c[i + (i >> 5)] = run; run += c8[k]; }
-        carry += total;
+        carry += total; carry64 += total;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RUN; k++) {
@@ -195,7 +196,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     }
     if (mx) atomicMax(&s_max, mx);
     __syncthreads();
-    if (tid == 0) { meta[0] = carry; meta[1] = s_max; }
+    if (tid == 0) { meta[0] = carry; meta[1] = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max; }      // (per-round totals stay below 2^32: 8192 tiles)
 }
 
 // (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count): entries of faces

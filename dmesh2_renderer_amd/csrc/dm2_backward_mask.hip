@@ -26,6 +26,7 @@
 // kernel returns at once and k_render_backward, launched behind it, does the work.
 #include <hip/hip_runtime.h>
 
+#include "dm2_bwd_shared.h"
 #include "dm2_clip_seg.h"
 #include "dm2_device_math.h"
 #include "dm2_dpp.h"
@@ -39,36 +40,7 @@ namespace dm2 {
 constexpr int BM_CAND = 32;      // candidate entries per chunk: two per 16-lane group of the cooperative record copy
 static_assert(BM_CAND * 4 <= TILE_PIX && 2 * BM_CAND <= 64, "one scan thread per (face, wave); one id window per wave");
 constexpr int BM_SLOTS = BM_CAND * 4;
-#ifndef DM2_BM_CARRY
-#define DM2_BM_CARRY 2         // phase D takes ray, corners, colours, NDC z of its pair from phase B2 in registers (0: re-reads LDS; A/B at cfg4: -3.7 %)
-#endif
-#ifndef DM2_BM_ACC
-#define DM2_BM_ACC 33       // odd pitch: the emit lanes of different faces add to different LDS banks (A/B at cfg4: 32 -> 33, -0.4 %)
-#endif
-constexpr int BM_ACC = DM2_BM_ACC;       // pitch of an accumulator row (dwords)
-constexpr int M_DV = 0, M_DC = 9, M_DZ = 18, M_OP = 21, M_IN = 22, M_AA = 23, M_N = 29, M_FLAG = 31;
-constexpr uint32_t MB_BLEND = 1u, MB_ACTIVE = 2u;
 constexpr int REC_CHUNKS = (int)(sizeof(FaceRec) / 16);   // 15 x 16 B of the 256-B global record are live
-
-struct __attribute__((aligned(16))) BmPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
-static_assert(sizeof(BmPair) == 32, "BmPair");
-
-// index of the n-th (0-based) set bit of m; n < popcount(m)
-__device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
-    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-    const int cl = __popc(lo);
-    const bool up = n >= cl;
-    const uint32_t w = up ? hi : lo;
-    n = up ? n - cl : n;
-    int pos = 0;
-#pragma unroll
-    for (int s = 16; s >= 1; s >>= 1) {
-        const int c = __popc((w >> pos) & ((1u << s) - 1u));
-        if (n >= c) { n -= c; pos += s; }
-    }
-    return pos + (up ? 32 : 0);
-}
-
 #ifndef DM2_BM_BLOCKS
 #define DM2_BM_BLOCKS 3       // resident blocks per CU the register budget is set for.  A/B at cfg4 on MI355X: 4 blocks (128 VGPRs) spill
                               // 39 registers to scratch, and a scratch reload waits for every LDS-direct load issued before it: 2.08 ms;
@@ -139,18 +111,8 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
 
     if (tid == 0) s_max_lc = 0;
-    if (tid < M_N) {   // flush table: component tid goes to  base + 4 * (id * mult),  id one of the record's (face_id, vid[0..2])
-        const int comp = tid;
-        const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
-        const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
-        const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
-        const int mult = g < 3 ? 3 : (g == 5 ? 6 : 1);
-        const int64_t add = g < 2 ? (int64_t)(within % 3) : g == 2 ? (int64_t)b * d.P * 3 + 2 : g == 3 ? (int64_t)0
-                          : g == 4 ? (int64_t)b * d.F : (int64_t)b * d.F * 6 + within;
-        s_fl_base[comp] = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
-                          : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
-        s_fl_sel[comp] = sel | (mult << 2);
-    }
+    if (tid < M_N) fill_flush_table(tid, b, d.P, d.F, dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense,
+                                    dL_daa_face_verts, s_fl_base, s_fl_sel);
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_lc, last_contributor);
     __syncthreads();
@@ -229,15 +191,18 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // pair; a running maximum spreads it (slots and their first pairs grow together); the slot that covers the wave's
         // first lane comes from a ballot
         const int lo_pair = wid * 64;
-        s_mark[wid][lane] = 0u;
+        // (volatile: the lanes of the wave talk to each other through this row with no barrier in between -- without it the
+        // compiler may forward this thread's own stores to its load)
+        volatile uint32_t* const mark_row = s_mark[wid];
+        mark_row[lane] = 0u;
         { const int r0 = b0 - lo_pair, r1 = b1 - lo_pair;
-          if (c0 > 0 && (uint32_t)r0 < 64u) s_mark[wid][r0] = ((uint32_t)(2 * lane + 1) << 9) | (uint32_t)b0;
-          if (c1 > 0 && (uint32_t)r1 < 64u) s_mark[wid][r1] = ((uint32_t)(2 * lane + 2) << 9) | (uint32_t)b1; }
+          if (c0 > 0 && (uint32_t)r0 < 64u) mark_row[r0] = ((uint32_t)(2 * lane + 1) << 9) | (uint32_t)b0;
+          if (c1 > 0 && (uint32_t)r1 < 64u) mark_row[r1] = ((uint32_t)(2 * lane + 2) << 9) | (uint32_t)b1; }
         uint32_t seed = 0u;
         { const unsigned long long e0 = __ballot(c0 > 0 && b0 <= lo_pair), e1 = __ballot(c1 > 0 && b1 <= lo_pair);
           if (e0) { const int l = 63 - __clzll((long long)e0); seed = ((uint32_t)(2 * l + 1) << 9) | (uint32_t)__builtin_amdgcn_readlane(b0, l); }
           if (e1) { const int l = 63 - __clzll((long long)e1); seed = max(seed, ((uint32_t)(2 * l + 2) << 9) | (uint32_t)__builtin_amdgcn_readlane(b1, l)); } }
-        const uint32_t mk = max(wave_inclusive_max(s_mark[wid][lane]), seed);
+        const uint32_t mk = max(wave_inclusive_max(mark_row[lane]), seed);
         STAMP(3)
 
         // ---- phase B2: one blending (pixel,face) pair per lane -------------------------------

@@ -244,16 +244,8 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
             // frame's forward left its blend masks (dm2_forward_queue.hip), dm2_backward_mask.hip uses them; otherwise (the
             // forward ran with DM2_FLAG_LEGACY_KERNELS) the per-pixel walk below does the work.
             StageTimer tm(ST_BWD, st);
-#ifndef DM2_BWD_STRIP
-#define DM2_BWD_STRIP 1       // 1: one wave per 4-row strip (dm2_backward_strip.hip); 0: one block per tile (dm2_backward_mask.hip), kept for A/B
-#endif
-#if DM2_BWD_STRIP
-            launch_render_backward_strip(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
-#else
             launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
                                         dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
-#endif
             const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
             hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
                                dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid);

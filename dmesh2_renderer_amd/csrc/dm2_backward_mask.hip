@@ -191,9 +191,9 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // pair; a running maximum spreads it (slots and their first pairs grow together); the slot that covers the wave's
         // first lane comes from a ballot
         const int lo_pair = wid * 64;
-        // (volatile: the lanes of the wave talk to each other through this row with no barrier in between -- without it the
-        // compiler may forward this thread's own stores to its load)
-        volatile uint32_t* const mark_row = s_mark[wid];
+        // (the lanes of the wave talk to each other through this row with no barrier in between: the fence below keeps the
+        // compiler from forwarding this thread's own stores to its load; the hardware runs a wave's LDS operations in order)
+        uint32_t* const mark_row = s_mark[wid];
         mark_row[lane] = 0u;
         { const int r0 = b0 - lo_pair, r1 = b1 - lo_pair;
           if (c0 > 0 && (uint32_t)r0 < 64u) mark_row[r0] = ((uint32_t)(2 * lane + 1) << 9) | (uint32_t)b0;
@@ -202,6 +202,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         { const unsigned long long e0 = __ballot(c0 > 0 && b0 <= lo_pair), e1 = __ballot(c1 > 0 && b1 <= lo_pair);
           if (e0) { const int l = 63 - __clzll((long long)e0); seed = ((uint32_t)(2 * l + 1) << 9) | (uint32_t)__builtin_amdgcn_readlane(b0, l); }
           if (e1) { const int l = 63 - __clzll((long long)e1); seed = max(seed, ((uint32_t)(2 * l + 2) << 9) | (uint32_t)__builtin_amdgcn_readlane(b1, l)); } }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const uint32_t mk = max(wave_inclusive_max(mark_row[lane]), seed);
         STAMP(3)
 

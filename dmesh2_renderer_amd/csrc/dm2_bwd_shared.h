@@ -1,5 +1,4 @@
-// dm2_bwd_shared.h -- what the two mask-driven backward kernels share (dm2_backward_mask.hip: one block per tile;
-// dm2_backward_strip.hip: one wave per 4-row strip of a tile).
+// dm2_bwd_shared.h -- constants, pair record and small helpers of the mask-driven backward kernel (dm2_backward_mask.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,9 +37,10 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
 
 // Flush table: component comp of an accumulator row goes to  base + 4 * (id * mult),  id one of the record's
 // (face_id, vid[0..2]) -- filled once per block by the lanes comp < M_N.
+template <class SelT>
 __device__ __forceinline__ void fill_flush_table(int comp, int b, int P, int F, float* dL_dverts, float* dL_dverts_color,
                                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                                 float* dL_daa_face_verts, float** fl_base, int* fl_sel) {
+                                                 float* dL_daa_face_verts, float** fl_base, SelT* fl_sel) {
     const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
     const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
     const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
@@ -49,7 +49,7 @@ __device__ __forceinline__ void fill_flush_table(int comp, int b, int P, int F, 
                       : g == 4 ? (int64_t)b * F : (int64_t)b * F * 6 + within;
     fl_base[comp] = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
                     : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
-    fl_sel[comp] = sel | (mult << 2);
+    fl_sel[comp] = (SelT)(sel | (mult << 2));
 }
 
 }  // namespace dm2

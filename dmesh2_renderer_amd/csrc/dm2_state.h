@@ -152,10 +152,6 @@ void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, 
                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                                  float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
-void launch_render_backward_strip(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
-                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                  float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,

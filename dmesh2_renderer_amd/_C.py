@@ -30,7 +30,7 @@ DM2_FLAG_CORRECTED_DV = 1
 DM2_FLAG_LEGACY_KERNELS = 2
 DM2_FLAG_NO_BACKWARD = 4
 DM2_FLAG_ANALYTIC_RAYS = 8
-SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE = 0, 1, 2, 3
+SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS = 0, 1, 2, 3, 4
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
 _flags = 0
@@ -79,7 +79,7 @@ EXPORTS = {
     "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dm2_prepare_faces": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp]),
     "dm2_prepare_faces_backward": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_debug_aa_overlap": (ctypes.c_int, [ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,7 +120,7 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dm2_abi_version() != 4:
+        if lib.dm2_abi_version() != 5:
             raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
         if path is None:
             _lib = lib
@@ -434,8 +434,9 @@ def generate_render_layers_cuda(width, height, verts, faces, tets, face_tets, te
             raise _err(lib, "generate_render_layers_cuda (plan)")
         R = int(nr.value)
         bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
+        tet_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_LAYER_TETS, T, 0))
         if lib.dm2_layers_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
-                              _ptr(img_buf), img_buf.numel(), _ptr(layers), _ptr(cnt), st):
+                              _ptr(img_buf), img_buf.numel(), _ptr(tet_buf), tet_buf.numel(), _ptr(layers), _ptr(cnt), st):
             raise _err(lib, "generate_render_layers_cuda (run)")
     generate_render_layers_cuda.last_debug = (R, face_buf, bin_buf, img_buf)      # kept for tests
     return layers, cnt

@@ -150,6 +150,7 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
         case DM2_SCRATCH_IMAGE: dm2::ImageState::carve(nullptr, count, aux, &total); break;
         case DM2_SCRATCH_BINNING: dm2::BinningState::carve(nullptr, count, dm2::sort_temp_bytes(count, aux), &total); break;
         case DM2_SCRATCH_LAYER_IMAGE: dm2::LayerImageState::carve(nullptr, count, aux, &total); break;
+        case DM2_SCRATCH_LAYER_TETS: return dm2::tet_scratch_bytes(count);
         default: return 0;
     }
     return total;
@@ -251,6 +252,7 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
 
 int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
                    void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                   void* tet_scratch, size_t tet_bytes,
                    int32_t* render_layers, int32_t* render_layers_cnt, void* stream) {
     if (check_layers_desc(d)) return 1;
     hipStream_t st = (hipStream_t)stream;
@@ -270,7 +272,8 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_t
     } else {
         DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
-    dm2::launch_layers(*d, fs, ls.ranges, bs.face_list, ls, render_layers, render_layers_cnt, st);
+    if (tet_scratch && dm2_scratch_bytes(DM2_SCRATCH_LAYER_TETS, d->T, 0) > tet_bytes) return fail("tet scratch too small");
+    dm2::launch_layers(*d, fs, ls.ranges, bs.face_list, ls, tet_scratch, render_layers, render_layers_cnt, st);
     DM2_HIP(hipGetLastError());
     return 0;
 }

@@ -159,8 +159,10 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
 void launch_debug_aa_overlap(int variant, int64_t n, const float* tv, const float* te, const uint8_t* tz, const float* tr,
                              const float* tn, const float* tc, const float* pixmin, float* area, float* grad, int32_t* code,
                              hipStream_t st);
+size_t tet_scratch_bytes(int64_t T);
+// tet_scratch (tet_scratch_bytes(T)) holds the packed per-tet records of the walk; nullptr = the reference-shaped walk
 void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,
-                   LayerImageState ls, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
+                   LayerImageState ls, void* tet_scratch, int32_t* render_layers, int32_t* render_layers_cnt, hipStream_t st);
 
 }  // namespace dm2
 

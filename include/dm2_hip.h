@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DM2_ABI_VERSION 4
+#define DM2_ABI_VERSION 5
 #define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
 
 /* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
@@ -91,7 +91,8 @@ enum {
                                  LayeredRenderer; tiles = ceil(W/16) * ceil(H/16) */
     DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
     DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
-    DM2_SCRATCH_LAYER_IMAGE = 3 /* count = B*H*W, aux = B*tiles    */
+    DM2_SCRATCH_LAYER_IMAGE = 3, /* count = B*H*W, aux = B*tiles    */
+    DM2_SCRATCH_LAYER_TETS = 4   /* count = T (tets): packed per-tet records of the layer walk, 256 B each */
 };
 
 int dm2_abi_version(void);
@@ -144,7 +145,7 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered,
 typedef struct dm2_layers_desc {
     int32_t B, P, F, T;
     int32_t W, H, L;              /* full frame width/height, num_layers */
-    int32_t flags;                /* DM2_FLAG_ANALYTIC_RAYS */
+    int32_t flags;                /* DM2_FLAG_ANALYTIC_RAYS, DM2_FLAG_LEGACY_KERNELS */
     const float* verts;           /* (P,3) */
     const int32_t* faces;         /* (F,3) */
     const int32_t* tets;          /* (T,4) */
@@ -161,11 +162,15 @@ typedef struct dm2_layers_desc {
 int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_bytes,
                     void* stream, int64_t* num_rendered, int64_t* max_tile_entries);
 /* render_layers (B,H,W,L) must be pre-filled with -1 and render_layers_cnt (B,H,W)
- * with 0 by the caller (render.cu:437-438). */
+ * with 0 by the caller (render.cu:437-438).  tet_scratch (DM2_SCRATCH_LAYER_TETS bytes for T tets; scratch of this call
+ * only) receives one packed 256-B record per tet -- face vertices, outward normals, neighbours, existence flags -- so
+ * that a step of the tet walk (forward.cu:853-996) is one contiguous fetch; NULL (or DM2_FLAG_LEGACY_KERNELS) selects the
+ * reference's access pattern.  Same layers either way. */
 int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries,
                    void* face_scratch, size_t face_bytes,
                    void* binning_scratch, size_t binning_bytes,
                    void* image_scratch, size_t image_bytes,
+                   void* tet_scratch, size_t tet_bytes,
                    int32_t* render_layers, int32_t* render_layers_cnt, void* stream);
 
 /* Host prep of Renderer.forward / LayeredRenderer.generate, fused.

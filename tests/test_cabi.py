@@ -20,7 +20,7 @@ def test_header_symbols_are_bound_and_exported():
     lib = _C.load_library()                       # raises if a declared symbol is missing
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.dm2_abi_version() == 4
+    assert lib.dm2_abi_version() == 5
 
 
 def test_structs_match_header_layout():

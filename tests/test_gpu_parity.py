@@ -229,8 +229,13 @@ def test_layers_exact():
     import dmesh2_renderer_amd as dm2
     scd = sc.to("cuda")
     lr = dm2.LayeredRenderer(scd.mv, scd.proj, W, H, "cuda")
-    for L in (4, 1):
-        layers, cnt = lr.generate([1, 0], scd.verts, scd.faces, scd.tets, scd.face_tets, scd.tet_faces, scd.faces_existence, L)
+    # both walks: over packed per-tet records (default) and with the reference's access pattern (DM2_FLAG_LEGACY_KERNELS)
+    for L, legacy in ((4, False), (1, False), (4, True), (2, True)):
+        old_flags = C.set_flags(C.DM2_FLAG_LEGACY_KERNELS if legacy else 0)
+        try:
+            layers, cnt = lr.generate([1, 0], scd.verts, scd.faces, scd.tets, scd.face_tets, scd.tet_faces, scd.faces_existence, L)
+        finally:
+            C.set_flags(old_flags)
         ndc, img = lr.compute_verts_ndc_image(scd.verts, scd.mv[[1, 0]], scd.proj[[1, 0]])
         ro, rd = lr.ray_o[[1, 0]], lr.ray_d[[1, 0]]
         rl, rc, rff, rft, bn = orc.generate_render_layers_cuda(

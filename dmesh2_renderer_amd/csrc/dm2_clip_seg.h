@@ -131,12 +131,14 @@ __device__ __forceinline__ float corner_chain_area(int c1, int k) {
 
 // Area and d(area)/d(corners) of pixel [pxmin,pxmax]x[pymin,pymax] and face f, for a pair whose reference clip
 // (aa.h:446-504) returns no error and a positive area.  g: [3][2] row-major.
+// inside_out: the pixel corners inside the triangle (aa.h:103-149), for a caller that wants the reference's own clip as well.
 __device__ __forceinline__ void seg_area_grad(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
-                                              float pix_area, float& area, float* g) {
+                                              float pix_area, float& area, float* g, uint32_t* inside_out = nullptr) {
 #pragma unroll
     for (int k = 0; k < 6; k++) g[k] = 0.f;
     uint32_t inside;
     classify_pixel(f, pxmin, pxmax, pymin, pymax, inside);            // aa.h:103-149 (the forward passed its all-outside test)
+    if (inside_out) *inside_out = inside;
     if (inside == 0xFu) { area = pix_area; return; }                  // aa.h:493-496: not clipped at all, zero Jacobian
     EdgeSeg S0, S1, S2;
     seg_edge<0>(f, pxmin, pxmax, pymin, pymax, inside, S0);

@@ -20,14 +20,18 @@ from oracle import cpu as orc  # noqa: E402
 GRAD_NAMES = ["verts", "verts_color", "faces_opacity", "verts_ndc", "faces_intense", "aa_face_verts"]
 
 
-def one_case(rng, idx):
+def one_case(seed, idx, verbose=False):
+    """Case `idx` of sweep `seed`: every random draw comes from (seed, idx), so a reported case can be replayed alone
+    (`python tests/fuzz_parity.py --case SEED IDX [legacy]`)."""
+    rng = np.random.default_rng([seed, idx])
+    torch.manual_seed(seed * 1000003 + idx)
     W, H = int(rng.integers(8, 220)), int(rng.integers(8, 160))
     F = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
     dc = float(rng.choice([0.3, 1.5, 4.0, 12.0, 40.0, 120.0]))
     temp = float(rng.choice([1.0, 1.0, 0.5, 0.25, 0.0]))
     K = int(rng.choice([0, 3, 20]))
     cams = int(rng.integers(1, 3))
-    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 1000 + idx, num_cams=cams, shared_verts=bool(rng.integers(0, 2)),
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 1000 + idx + 7919 * seed, num_cams=cams, shared_verts=bool(rng.integers(0, 2)),
                               depth_complexity=dc)
     if rng.integers(0, 3) == 0:          # opaque faces: alpha == 1 branch, early termination
         sc.faces_opacity = torch.where(torch.rand(F) < 0.5, torch.ones(F), sc.faces_opacity)
@@ -48,6 +52,13 @@ def one_case(rng, idx):
                                 out[7], out[8], out[9], out[3], out[4], out[5], out[6])
     gref = orc.render_backward_cuda(ref, gc, gd, nthreads=orc.max_threads())
     worst = max(rel_linf(x.cpu().numpy(), gref[n]) for x, n in zip(g, GRAD_NAMES))
+    if verbose:
+        print(desc, "forward ok:", ok)
+        for x, n in zip(g, GRAD_NAMES):
+            a, r = x.cpu().numpy(), gref[n]
+            dif = np.abs(a - r)
+            k = np.unravel_index(int(dif.argmax()), dif.shape) if dif.size else ()
+            print(f"  {n:14s} rel L_inf {rel_linf(a, r):.3e}  max |ref| {np.abs(r).max() if r.size else 0:.4g}  worst element {k}: hip {a[k] if dif.size else 0:.7g} ref {r[k] if dif.size else 0:.7g}")
     if worst > 1e-5:
         # A face that covers thousands of pixels sums thousands of fp32 terms, and with random-sign upstream gradients
         # the sum can be orders of magnitude smaller than its terms (a single face's opacity / intensity gradient
@@ -65,7 +76,9 @@ def one_case(rng, idx):
         # test_fuzz4_regression derives it on the one case this sweep ever flagged); large patches: the ratio to the fp32
         # oracle's own distance from fp64.  The TRUE e_hip stays in the returned worst value either way.
         accepted = e_hip <= max(1e-5, 32.0 * e_orc)
-        if len(bidx) == 1 and pw * ph <= 4096:
+        if e_hip <= 1.5 * e_orc:
+            pass                      # no farther from the fp64 result than the reference-order fp32 computation itself
+        elif len(bidx) == 1 and pw * ph <= 4096:
             from test_gpu_coverage import per_pixel_terms_f64
             sabs = per_pixel_terms_f64(args, gc, gd, pm, pw, ph)
             accepted = all((np.abs(x.cpu().numpy() - g64[n]) <= 1e-5 * max(float(np.abs(g64[n]).max()), 1e-12) + 8 * 2.0 ** -24 * sabs[n]).all()
@@ -76,22 +89,26 @@ def one_case(rng, idx):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--case":
+        seed, idx = int(sys.argv[2]), int(sys.argv[3])
+        _C.set_flags(_C.DM2_FLAG_LEGACY_KERNELS if len(sys.argv) > 4 else 0)
+        print(one_case(seed, idx, verbose=True))
+        return
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    rng = np.random.default_rng(seed)
     t0, n, worst_all, bad = time.time(), 0, 0.0, []
     for legacy in (0, _C.DM2_FLAG_LEGACY_KERNELS):
         _C.set_flags(legacy)
         t1 = time.time()
         while time.time() - t1 < budget / 2:
-            ok, worst, desc = one_case(rng, n)
+            ok, worst, desc = one_case(seed, n)
             n += 1
             if n % 200 == 0:          # a heartbeat: a long silent GPU run is taken to be hung
                 print(f"... {n} cases, {time.time() - t0:.0f} s, worst so far {max(worst_all, worst):.2e}", flush=True)
             worst_all = max(worst_all, worst)             # the true worst error, accepted or not
             if not ok or (worst > 1e-5 and not desc.get("accepted_as_summation_noise", False)):
                 bad.append((legacy, ok, worst, desc))
-                print("MISMATCH", legacy, ok, worst, desc, flush=True)
+                print("MISMATCH", legacy, ok, worst, dict(desc, seed=seed, idx=n - 1), flush=True)
     _C.set_flags(0)
     print(f"{n} cases in {time.time() - t0:.0f} s, worst gradient rel L_inf {worst_all:.2e} (vs the fp64 oracle where it exceeds 1e-5 "
           f"of the fp32 one), mismatches: {len(bad)}")

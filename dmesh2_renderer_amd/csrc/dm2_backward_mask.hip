@@ -27,7 +27,6 @@
 #include <hip/hip_runtime.h>
 
 #include "dm2_bwd_shared.h"
-#include "dm2_clip_area.h"
 #include "dm2_clip_seg.h"
 #include "dm2_device_math.h"
 #include "dm2_dpp.h"
@@ -232,9 +231,15 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             // face's plane and the coverage was not 0.  Those decisions are NOT taken again here (the segment formulation
             // may round an area of 1e-9 to 0, or 1 to 1 - 1 ulp): a pair of the masks is replayed whatever the values say,
             // otherwise the per-pixel replay below would lose its place in the list.
+            // The replay divides the running T by (1 - alpha) (backward.cu:340-348) and the background term by it once more
+            // (backward.cu:396-401): an error of one ulp in alpha is an error of ulp / (1 - alpha) in both.  The segment
+            // formulation's shoelace area is good to 2 ulp of the pixel area (2.4e-7): at most 2.4e-6 of T per entry up to
+            // alpha = 0.9, but a nearly opaque, nearly covering face needs the forward's alpha to the bit (found by the
+            // randomised sweep: opacity 1, coverage 0.999998, 1.3 % error in one opacity gradient).  alpha <= opacity, so
+            // faces with opacity > 0.9 get the reference's fan sum over the same corners -- the forward's area exactly
+            // (dm2_clip_seg.h); a wave without such a face skips it (the benchmark scene, opacities up to 0.9, always does).
             float oarea;
-            uint32_t inside_mask;
-            seg_area_grad(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, dg, &inside_mask);
+            seg_area_grad(fc.aa, pxmin, pxmax, pymin, pymax, pix_area, oarea, dg, fc.opacity > 0.9f);
             oarea = fmaxf(oarea, 0.0f);
             BmPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
             ratio = oarea / pix_area;
@@ -261,23 +266,6 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
                 out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
                 alpha = fc.opacity * ratio;
-                // The replay divides the running T by (1 - alpha) (backward.cu:340-348) and the background term by it once
-                // more (backward.cu:396-401): an error of one ulp in alpha is an error of ulp / (1 - alpha) in both.  The
-                // segment formulation's area is good to 2 ulp of the pixel area (2.4e-7): at most 2.4e-6 of T per entry up to
-                // alpha = 0.9, but a nearly opaque, nearly covering face needs the forward's alpha to the bit (found by the
-                // randomised sweep: opacity 1, coverage 0.999998, 1.3 % error in one opacity gradient).  For pairs with
-                // alpha > 0.9 the reference's own clip runs as well, exactly as in the forward; a wave without such a pair
-                // skips it (the benchmark scene, opacities up to 0.9, never takes it; A/B with the threshold at 0.75, which
-                // it does reach: 1.33 -> 1.55 ms).
-                const bool exact = alpha > 0.9f && inside_mask != 0xFu;
-                if (__any(exact)) {
-                    if (exact) {
-                        float ex = 0.f;
-                        (void)clip_area_classified(fc.aa, pxmin, pxmax, pymin, pymax, inside_mask, pix_area, ex);   // (the forward accepted it)
-                        ratio = mix_coverage(code, ex / pix_area, temp);
-                        alpha = fc.opacity * ratio;
-                    }
-                }
                 out.alpha = alpha;
                 out.flags = MB_BLEND;
                 blend = true;

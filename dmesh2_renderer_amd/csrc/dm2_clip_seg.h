@@ -25,8 +25,9 @@
 //     polynomial in the same corner coordinates, regrouped: agrees with the oracle to ~1e-6 absolute.
 //   * Area: shoelace over the same cyclic sequence in pixel-local coordinates (the subtraction of the pixel
 //     origin is exact); the pixel-corner chain contributes 1/2 per traversed x = xmax or y = ymax edge.
-//     Agrees with the reference's fan sum to 2 ulp of the pixel area; the backward only needs alpha to that
-//     accuracy (the blend decision itself is the forward's, never re-taken).
+//     Agrees with the reference's fan sum to 2 ulp of the pixel area; enough for alpha up to ~0.9 (the blend decision
+//     itself is the forward's, never re-taken).  For nearly opaque faces the caller asks for `exact_area`: the fan sum
+//     itself over the same corners, bit-identical to the forward's area.
 //
 // tests/test_gpu_clippers.py runs this function on the reference-produced vectors (tests/golden/aa_pairs.npz,
 // aa_error_pairs.npz), on random pairs and on exact-tie stress sets through dm2_debug_aa_overlap.
@@ -131,14 +132,16 @@ __device__ __forceinline__ float corner_chain_area(int c1, int k) {
 
 // Area and d(area)/d(corners) of pixel [pxmin,pxmax]x[pymin,pymax] and face f, for a pair whose reference clip
 // (aa.h:446-504) returns no error and a positive area.  g: [3][2] row-major.
-// inside_out: the pixel corners inside the triangle (aa.h:103-149), for a caller that wants the reference's own clip as well.
+// exact_area (per lane): also run the reference's fan sum over the rebuilt corners -- the same corners in the same order
+// through the forward's own fan_push (dm2_clip_area.h), hence the forward's area TO THE BIT instead of the shoelace's 2 ulp.
+// The backward needs that where alpha is close to 1 (an ulp of alpha is ulp / (1 - alpha) of the replayed T); the pass is
+// skipped by a wave none of whose lanes asks for it.
 __device__ __forceinline__ void seg_area_grad(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
-                                              float pix_area, float& area, float* g, uint32_t* inside_out = nullptr) {
+                                              float pix_area, float& area, float* g, bool exact_area = false) {
 #pragma unroll
     for (int k = 0; k < 6; k++) g[k] = 0.f;
     uint32_t inside;
     classify_pixel(f, pxmin, pxmax, pymin, pymax, inside);            // aa.h:103-149 (the forward passed its all-outside test)
-    if (inside_out) *inside_out = inside;
     if (inside == 0xFu) { area = pix_area; return; }                  // aa.h:493-496: not clipped at all, zero Jacobian
     EdgeSeg S0, S1, S2;
     seg_edge<0>(f, pxmin, pxmax, pymin, pymax, inside, S0);
@@ -154,9 +157,23 @@ __device__ __forceinline__ void seg_area_grad(const AAFace& f, float pxmin, floa
     const float N1x = sel(S2.has, S2.ax, S0.has, S0.ax, S1.ax), N1y = sel(S2.has, S2.ay, S0.has, S0.ay, S1.ay);
     const float N2x = sel(S0.has, S0.ax, S1.has, S1.ax, S2.ax), N2y = sel(S0.has, S0.ay, S1.has, S1.ay, S2.ay);
     float a2 = 0.f;                                                   // twice the area
+    // exact_area: the reference's fan sum in its emission order (aa.h:304-379): per edge [entry crossing] [exit crossing |
+    // end point] [pixel corners], streamed through the forward's fan_push while the edge's corners are at hand
+    const bool do_fan = __any(exact_area);                            // wave-uniform
+    FanState F;
+    F.fx = F.fy = F.px = F.py = 0.f; F.area = 0.f; F.cnt = 0; F.err = false;
     auto edge = [&](auto ti, const EdgeSeg& S, float Px, float Py, float Nx, float Ny) {
         constexpr int TI = decltype(ti)::value;
         constexpr int TJ = (TI + 1) % 3;
+        if (do_fan) {
+            fan_push(F, exact_area && S.has && S.sX, S.sx, S.sy);
+            fan_push(F, exact_area && S.has, S.ex, S.ey);
+#pragma unroll
+            for (int pvi = 0; pvi < 3; pvi++) {                       // at most three: inside != 0xF
+                const int cur = (S.epe + 1 + pvi) & 3;
+                fan_push(F, exact_area && (pvi < S.k), (cur == 1 || cur == 2) ? pxmax : pxmin, (cur >= 2) ? pymax : pymin);
+            }
+        }
         // first emitted corner when it is the entry crossing: neighbours = (last corner before this edge, the second corner)
         seg_push_crossing<TI>(f, S.has && S.sX, S.spe, S.st, pxmin, pxmax, pymin, pymax, 0.5f * (S.ey - Py), 0.5f * (Px - S.ex), g);
         // last emitted non-pixel corner: previous = the entry crossing or the last corner before this edge; next = the first
@@ -180,6 +197,7 @@ __device__ __forceinline__ void seg_area_grad(const AAFace& f, float pxmin, floa
     edge(std::integral_constant<int, 1>{}, S1, P1x, P1y, N1x, N1y);
     edge(std::integral_constant<int, 2>{}, S2, P2x, P2y, N2x, N2y);
     area = 0.5f * a2;
+    if (do_fan && exact_area) area = F.area;
 }
 
 }  // namespace dm2

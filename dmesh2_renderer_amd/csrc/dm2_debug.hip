@@ -39,7 +39,7 @@ k_debug_aa_overlap(int variant, int64_t n, const float* __restrict__ tv, const f
     } else {                           // backward (dm2_backward_mask.hip): the forward's decision, then the segment formulation
         float af = 0.f;
         err = tri_pix_overlap_area_only(f, pxmin, pxmax, pymin, pymax, 1.0f, af);
-        if (err == 0 && af != 0.0f) seg_area_grad(f, pxmin, pxmax, pymin, pymax, 1.0f, a, g);
+        if (err == 0 && af != 0.0f) seg_area_grad(f, pxmin, pxmax, pymin, pymax, 1.0f, a, g, variant == 3);   // 3: with the exact fan-sum area
     }
     if (err != 0) { a = 0.f; for (int k = 0; k < 6; k++) g[k] = 0.f; }
     area[i] = a; code[i] = err;

@@ -218,7 +218,8 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
  * Triangles builds them (pyrenderer.py:6-30), n x the per-face layout of dm2_render_desc; pixmin (n,2) float: the
  * pixel's (x, y) origin, unit size.  variant 0: the generic clipper of the per-pixel-walk kernels, area + Jacobian in
  * the reference's order (aa.h:151-504); 1: the forward's area-only clipper; 2: the forward's accept / reject decision,
- * then the backward's segment formulation of area + Jacobian.  Outputs: area (n), grad (n,3,2), code (n) int32 --
+ * then the backward's segment formulation of area + Jacobian; 3: the same with the reference's fan sum over its corners
+ * (the area bit-identical to the forward's, what the backward uses for faces with opacity > 0.9).  Outputs: area (n), grad (n,3,2), code (n) int32 --
  * 0 = no error, non-zero = the reference reports one of its errors E00..E05 (dmesh2_renderer/README.md; the
  * composite kernels only ever test != 0); area and grad are zero where code != 0. */
 int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, const float* aa_face_edges,

@@ -5,7 +5,8 @@ each of its exceptions "Error code 00".."05" plus near-tie inputs it accepts), t
 
 Bars: the generic clipper of the per-pixel-walk kernels (variant 0) and the forward's straight-line area clipper
 (variant 1) are bit-equal to the CPU oracle -- area, and for variant 0 the Jacobian in the reference's fan order; the
-backward's segment formulation (variant 2; the same polynomial regrouped, see dm2_clip_seg.h) agrees to 2 ulp of the
+backward's segment formulation (variant 2; the same polynomial regrouped, see dm2_clip_seg.h; variant 3: with the
+reference's fan sum over its corners, the area bit-equal as well) agrees to 2 ulp of the
 pixel area and 1e-6 absolute in the Jacobian.  All three report an error exactly where the reference raises."""
 import os
 
@@ -59,7 +60,7 @@ def _oracle_run(g):
 
 
 @pytest.mark.parametrize("name", ["aa_pairs.npz", "aa_error_pairs.npz"])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_device_clipper_on_reference_vectors(name, variant):
     g = _load(name)
     ref_err = np.array([bool(m) for m in g["msg_analytic"]])
@@ -70,13 +71,13 @@ def test_device_clipper_on_reference_vectors(name, variant):
     assert np.array_equal(code != 0, ref_err), np.where((code != 0) != ref_err)[0]
     assert np.array_equal(o_code != 0, ref_err)
     ok = ~ref_err
-    if variant in (0, 1):
+    if variant in (0, 1, 3):      # 3: the segment formulation with the reference's fan sum over its corners: the area to the bit
         assert np.array_equal(area.view(np.uint32), o_area.view(np.uint32)), np.abs(area - o_area).max()
     else:
         assert np.abs(area - o_area).max() <= SEG_AREA_TOL, np.abs(area - o_area).max()
     if variant == 0:
         assert np.array_equal(grad.view(np.uint32), o_grad.view(np.uint32)), np.abs(grad - o_grad).max()
-    elif variant == 2:
+    elif variant in (2, 3):
         # a pair whose area is exactly 0 never blends (forward.cu:337-338): the backward never sees it, the hook returns zeros
         ok = ok & (o_area != 0)
         assert _grad_err(grad, o_grad)[ok].max() <= SEG_GRAD_TOL, _grad_err(grad, o_grad)[ok].max()
@@ -127,11 +128,13 @@ def test_device_clippers_random_pairs(base, radius):
     o_area, o_grad, o_code = _oracle_run(g)
     partial = (o_code == 0) & (o_area > 0) & (o_area < 1)
     assert partial.sum() >= 40, partial.sum()
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         area, grad, code = _device_run(g, variant)
         assert np.array_equal(code != 0, o_code != 0), variant
-        if variant == 2:
+        if variant >= 2:
             live = (o_code == 0) & (o_area != 0)
+            if variant == 3:      # exact_area: the reference's fan sum over the rebuilt corners, bit for bit
+                assert np.array_equal(area[live].view(np.uint32), o_area[live].view(np.uint32)), np.abs(area - o_area)[live].max()
             assert np.abs(area - o_area).max() <= SEG_AREA_TOL, (variant, np.abs(area - o_area).max())
             assert _grad_err(grad, o_grad)[live].max() <= SEG_GRAD_TOL, (variant, _grad_err(grad, o_grad)[live].max())
         else:
@@ -188,11 +191,13 @@ def test_device_clippers_exact_ties():
     with np.errstate(all="ignore"):
         o_area, o_grad, o_code = _oracle_run(g)
     assert (o_code != 0).sum() >= 1500 and ((o_code == 0) & (o_area > 0) & (o_area < 1)).sum() >= 4000
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         area, grad, code = _device_run(g, variant)
         assert np.array_equal(code != 0, o_code != 0), variant
-        if variant == 2:
+        if variant >= 2:
             live = (o_code == 0) & (o_area != 0)
+            if variant == 3:
+                assert np.array_equal(area[live].view(np.uint32), o_area[live].view(np.uint32)), np.abs(area - o_area)[live].max()
             assert np.abs(area - o_area).max() <= SEG_AREA_TOL, np.abs(area - o_area).max()
             assert _grad_err(grad, o_grad)[live].max() <= SEG_GRAD_TOL, _grad_err(grad, o_grad)[live].max()
         else:

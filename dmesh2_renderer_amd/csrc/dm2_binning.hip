@@ -39,17 +39,21 @@ namespace dm2 {
 // that hit the same tile -- neighbouring faces of a mesh, a tet lattice -- are grouped first: the group's first lane adds the
 // group's size, the others take the consecutive places.  Grouping costs a few scalar instructions per distinct tile; a
 // probe skips it where hardly any lanes share (a triangle soup).  Call with the whole wave (act = lane has a tile).
+// Two halves when the place is wanted: `issue` fires the atomic and returns at once (TilePlace holds the pending return
+// value), `finish` reads it -- so that a caller's atomics are all in flight together and their latency hides behind
+// whatever it does in between.
+struct TilePlace { uint32_t base; int leader; uint32_t offset; };
 template <bool RANK, int STRIDE>
-__device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, bool act) {
-    const unsigned long long all = __ballot(act);
-    if (all == 0) return 0u;
+__device__ __forceinline__ TilePlace wave_count_tiles_issue(uint32_t* cnt, uint32_t t, bool act) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    TilePlace p; p.base = 0u; p.leader = lane; p.offset = 0u;
+    const unsigned long long all = __ballot(act);
+    if (all == 0) return p;
     const int l0 = __ffsll((long long)all) - 1;
     const unsigned long long m0 = __ballot(act && t == (uint32_t)__builtin_amdgcn_readlane((int)t, l0));
-    if (__popcll(m0) * 8 <= __popcll(all)) {
-        uint32_t r = 0;
-        if (act) { if (RANK) r = atomicAdd(cnt + (int64_t)STRIDE * t, 1u); else atomicAdd(cnt + (int64_t)STRIDE * t, 1u); }
-        return r;
+    if (__popcll(m0) * 8 <= __popcll(all)) {                              // hardly any sharing: every lane for itself
+        if (act) { if (RANK) p.base = atomicAdd(cnt + (int64_t)STRIDE * t, 1u); else atomicAdd(cnt + (int64_t)STRIDE * t, 1u); }
+        return p;
     }
     unsigned long long todo = all, mine = 0;
     while (todo) {
@@ -59,15 +63,23 @@ __device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, 
         if (act && t == tl) mine = m;
         todo &= ~m;
     }
-    const int leader = act ? __ffsll((long long)mine) - 1 : lane;
-    uint32_t base = 0;
-    if (act && lane == leader) {
-        if (RANK) base = atomicAdd(cnt + (int64_t)STRIDE * t, (uint32_t)__popcll(mine));
+    p.leader = act ? __ffsll((long long)mine) - 1 : lane;
+    if (act && lane == p.leader) {
+        if (RANK) p.base = atomicAdd(cnt + (int64_t)STRIDE * t, (uint32_t)__popcll(mine));
         else atomicAdd(cnt + (int64_t)STRIDE * t, (uint32_t)__popcll(mine));
     }
-    if (!RANK) return 0u;
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    p.offset = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    return p;
+}
+// the lane's place: the group's base (held by its first lane; the lane itself when it counted alone) + its rank in the group.
+// Call with the whole wave.
+__device__ __forceinline__ uint32_t wave_count_tiles_finish(const TilePlace& p) {
+    return (uint32_t)__shfl((int)p.base, p.leader) + p.offset;
+}
+template <bool RANK, int STRIDE>
+__device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, bool act) {
+    const TilePlace p = wave_count_tiles_issue<RANK, STRIDE>(cnt, t, act);
+    return RANK ? wave_count_tiles_finish(p) : 0u;
 }
 
 // PACK: also write the face's packed record (dm2_stage.h) for the composite kernels -- only for faces that reach a
@@ -107,6 +119,9 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
         }
     }
+    const bool small = touched != 0 && touched <= 4;
+    const bool any_small = __ballot(small) != 0ull;
+    TilePlace place[4];
     {
         // entries per tile (the lists' sizes).  A face with at most four tiles -- nearly all of a fine mesh -- takes its
         // place inside each tile's segment right here (the atomic's return value) and keeps it for k_bin_scatter, which
@@ -114,17 +129,15 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
         // (wave-uniform control flow from here to the end of the block: wave_count_tiles is a wave-wide operation)
         const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
         const uint32_t tb = (uint32_t)((int64_t)gx * gy * b);
-        const bool small = touched != 0 && touched <= 4, big = touched > 4;
-        if (__ballot(small)) {
+        const bool big = touched > 4;
+        if (any_small) {
             const uint32_t w = x1 - x0;                                       // entry k (rect order): tile (x0 + k % w, y0 + k / w)
-            uint32_t rk[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
+            for (uint32_t k = 0; k < 4; k++) {                                // four atomics in flight; their places are read at the very end
                 const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
                 const bool act = small && k < touched;
-                rk[k] = wave_count_tiles<true, 1>(fs.tile_cnt, act ? tb + ((y0 + ky) * gx + x0 + kx) : 0u, act);
+                place[k] = wave_count_tiles_issue<true, 1>(fs.tile_cnt, act ? tb + ((y0 + ky) * gx + x0 + kx) : 0u, act);
             }
-            if (small) fs.tile_rank[idx] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
         }
         if (__ballot(big)) {
             uint32_t cx = x0, cy = y0;
@@ -147,6 +160,11 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
         uint4* dst = fs.recs + idx * FACE_REC_U4;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
+    }
+    if (any_small) {                                                       // (wave-uniform: the shuffles need the whole wave)
+        const uint32_t r0 = wave_count_tiles_finish(place[0]), r1 = wave_count_tiles_finish(place[1]);
+        const uint32_t r2 = wave_count_tiles_finish(place[2]), r3 = wave_count_tiles_finish(place[3]);
+        if (small) fs.tile_rank[idx] = make_uint4(r0, r1, r2, r3);
     }
 }
 

@@ -43,15 +43,22 @@ namespace dm2 {
 // value), `finish` reads it -- so that a caller's atomics are all in flight together and their latency hides behind
 // whatever it does in between.
 struct TilePlace { uint32_t base; int leader; uint32_t offset; };
+// do the lanes of the wave share tiles? (the probe: how many have the first active lane's tile)
+__device__ __forceinline__ bool wave_tiles_shared(uint32_t t, bool act) {
+    const unsigned long long all = __ballot(act);
+    if (all == 0) return false;
+    const int l0 = __ffsll((long long)all) - 1;
+    const unsigned long long m0 = __ballot(act && t == (uint32_t)__builtin_amdgcn_readlane((int)t, l0));
+    return __popcll(m0) * 8 > __popcll(all);
+}
+// grouped: the (wave-uniform) answer of wave_tiles_shared for these lanes, or for related tiles of the same lanes
 template <bool RANK, int STRIDE>
-__device__ __forceinline__ TilePlace wave_count_tiles_issue(uint32_t* cnt, uint32_t t, bool act) {
+__device__ __forceinline__ TilePlace wave_count_tiles_issue(uint32_t* cnt, uint32_t t, bool act, bool grouped) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     TilePlace p; p.base = 0u; p.leader = lane; p.offset = 0u;
     const unsigned long long all = __ballot(act);
     if (all == 0) return p;
-    const int l0 = __ffsll((long long)all) - 1;
-    const unsigned long long m0 = __ballot(act && t == (uint32_t)__builtin_amdgcn_readlane((int)t, l0));
-    if (__popcll(m0) * 8 <= __popcll(all)) {                              // hardly any sharing: every lane for itself
+    if (!grouped) {                                                       // hardly any sharing: every lane for itself
         if (act) { if (RANK) p.base = atomicAdd(cnt + (int64_t)STRIDE * t, 1u); else atomicAdd(cnt + (int64_t)STRIDE * t, 1u); }
         return p;
     }
@@ -78,7 +85,7 @@ __device__ __forceinline__ uint32_t wave_count_tiles_finish(const TilePlace& p) 
 }
 template <bool RANK, int STRIDE>
 __device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, bool act) {
-    const TilePlace p = wave_count_tiles_issue<RANK, STRIDE>(cnt, t, act);
+    const TilePlace p = wave_count_tiles_issue<RANK, STRIDE>(cnt, t, act, wave_tiles_shared(t, act));
     return RANK ? wave_count_tiles_finish(p) : 0u;
 }
 
@@ -132,11 +139,12 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
         const bool big = touched > 4;
         if (any_small) {
             const uint32_t w = x1 - x0;                                       // entry k (rect order): tile (x0 + k % w, y0 + k / w)
+            const bool grouped = wave_tiles_shared(tb + (y0 * gx + x0), small);   // one probe (the faces' first tiles) for all four
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {                                // four atomics in flight; their places are read at the very end
                 const uint32_t ky = w == 1 ? k : (w == 2 ? k >> 1 : (w == 3 ? (k == 3 ? 1u : 0u) : 0u)), kx = k - ky * w;
                 const bool act = small && k < touched;
-                place[k] = wave_count_tiles_issue<true, 1>(fs.tile_cnt, act ? tb + ((y0 + ky) * gx + x0 + kx) : 0u, act);
+                place[k] = wave_count_tiles_issue<true, 1>(fs.tile_cnt, act ? tb + ((y0 + ky) * gx + x0 + kx) : 0u, act, grouped);
             }
         }
         if (__ballot(big)) {

@@ -104,6 +104,11 @@ k_aa_scatter(int P, int F, float Wf, float Hf, const float* __restrict__ verts, 
     const int b = blockIdx.y;
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    const float2* g = reinterpret_cast<const float2*>(g_aa) + ((int64_t)b * F + f) * 3;
+    const float2 g0 = g[0], g1 = g[1], g2 = g[2];
+    // a face the rasteriser never listed (culled, outside the patch or -- multi-GPU -- outside this rank's band) has an
+    // all-zero row: nothing to scatter, and no need to project its corners to find their order
+    if (g0.x == 0.f && g0.y == 0.f && g1.x == 0.f && g1.y == 0.f && g2.x == 0.f && g2.y == 0.f) return;
     const int v0 = faces[3 * (int64_t)f], v1 = faces[3 * (int64_t)f + 1], v2 = faces[3 * (int64_t)f + 2];
     const int vs[3] = {v0, v1, v2};
     float2 p[3];
@@ -114,11 +119,11 @@ k_aa_scatter(int P, int F, float Wf, float Hf, const float* __restrict__ verts, 
     }
     const bool flip = is_clockwise(p[0], p[1], p[2]);
     const int dst[3] = {v0, flip ? v2 : v1, flip ? v1 : v2};
-    const float2* g = reinterpret_cast<const float2*>(g_aa) + ((int64_t)b * F + f) * 3;
     float* gi = g_image + (int64_t)b * P * 2;
+    const float2 gs[3] = {g0, g1, g2};
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const float2 gv = g[i];
+        const float2 gv = gs[i];
         atomicAdd(gi + 2 * (int64_t)dst[i], gv.x);
         atomicAdd(gi + 2 * (int64_t)dst[i] + 1, gv.y);
     }

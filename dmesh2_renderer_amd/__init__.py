@@ -161,12 +161,25 @@ class Renderer(torch.nn.Module):
         d = target - self.ray_o
         self.ray_d = d / (torch.norm(d, dim=-1, keepdim=True) + 1e-6)
 
+    def _camera_rows(self, t, batch_mvp_idx):
+        """t[batch_mvp_idx] -- as a view (no copy) when the cameras are one or a run of consecutive ones."""
+        idx = [int(i) for i in batch_mvp_idx]
+        if idx and all(idx[k + 1] == idx[k] + 1 for k in range(len(idx) - 1)) and 0 <= idx[0] and idx[-1] < t.shape[0]:
+            return t[idx[0]:idx[0] + len(idx)]
+        return t[idx]
+
     def select_rays(self, batch_mvp_idx, batch_patch_min, patch_width, patch_height):
         """Rays of the (patch_height, patch_width) window at patch_min of each batch item (reference :264-302)."""
+        # one read-back of the (B,2) patch origins serves the reference's two bound checks (same messages) and tells whether
+        # every window is the whole frame -- then the ray tensors are handed over as views, not gathered into a copy
+        # (2 x 24.9 MB per camera at 1080p)
+        pm = [[int(v) for v in row] for row in batch_patch_min.tolist()]
+        assert all(p[0] + patch_width <= self.width for p in pm), "Some b_patch_max_x exceed self.width"
+        assert all(p[1] + patch_height <= self.height for p in pm), "Some b_patch_max_y exceed self.height"
+        if patch_width == self.width and patch_height == self.height and all(p[0] == 0 and p[1] == 0 for p in pm):
+            return self._camera_rows(self.ray_o, batch_mvp_idx), self._camera_rows(self.ray_d, batch_mvp_idx)
         px0 = batch_patch_min[:, 0].long()
         py0 = batch_patch_min[:, 1].long()
-        assert (px0 + patch_width <= self.width).all(), "Some b_patch_max_x exceed self.width"
-        assert (py0 + patch_height <= self.height).all(), "Some b_patch_max_y exceed self.height"
         dev = self.ray_o.device
         cams = torch.as_tensor(list(batch_mvp_idx), device=dev, dtype=torch.long)
         rows = py0.to(dev).view(-1, 1, 1) + torch.arange(patch_height, device=dev).view(1, -1, 1)
@@ -279,7 +292,7 @@ class LayeredRenderer(Renderer):
                 return _C.generate_render_layers_cuda(
                     self.width, self.height, verts.to(f32), faces.to(i32), tets.to(i32), face_tets.to(i32), tet_faces.to(i32),
                     faces_existence.to(i32), verts_ndc.to(f32), verts_image.to(f32), ph, ph, num_layers)
-        ray_o, ray_d = self.ray_o[batch_mvp_idx], self.ray_d[batch_mvp_idx]
+        ray_o, ray_d = self._camera_rows(self.ray_o, batch_mvp_idx), self._camera_rows(self.ray_d, batch_mvp_idx)
         return _C.generate_render_layers_cuda(
             self.width, self.height,
             verts.to(f32), faces.to(i32), tets.to(i32), face_tets.to(i32), tet_faces.to(i32),

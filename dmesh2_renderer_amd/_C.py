@@ -358,11 +358,13 @@ def render_backward_cuda(*args):
     d, dev, (B, P, F, W, H, K) = _make_desc(fwd_args, keep)
     _require_gpu(dL_dcolor, dL_ddepth)
     f32 = torch.float32
-    sizes = [P * 3, P * 3, F, B * P * 3, B * F, B * F * 6]
+    # physical order: the gradients of the LEAVES first ([dverts | dverts_color | dfaces_opacity | dfaces_intense], one
+    # contiguous span for a multi-GPU caller), then the two intermediates of the host prep (dverts_ndc, daa_face_verts)
+    sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * F * 6]
     packed = torch.zeros((sum(sizes),), dtype=f32, device=dev)          # render.cu:313-318 zeros_like x6
     parts = torch.split(packed, sizes)
     g_verts = parts[0].view(P, 3); g_color = parts[1].view(P, 3); g_opac = parts[2].view(F)
-    g_ndc = parts[3].view(B, P, 3); g_int = parts[4].view(B, F); g_aa = parts[5].view(B, F, 3, 2)
+    g_int = parts[3].view(B, F); g_ndc = parts[4].view(B, P, 3); g_aa = parts[5].view(B, F, 3, 2)
     if F != 0 and P != 0 and num_rendered > 0 and B * H * W > 0:
         if tuple(dL_dcolor.shape) != (B, H, W, 3) or tuple(dL_ddepth.shape) != (B, H, W):
             raise RuntimeError("dL_dout_color / dL_dout_depth must have dimensions (B, H, W, 3) / (B, H, W)")

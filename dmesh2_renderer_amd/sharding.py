@@ -188,11 +188,12 @@ class BandShardedOp:
         if self.rows == 0:
             P, F, B = a[4].shape[0], a[5].shape[0], a[8].shape[0]
             dev = a[4].device
-            sizes = [P * 3, P * 3, F, B * P * 3, B * F, B * F * 6]
+            # (the physical order of _C.render_backward_cuda: every rank must take the same path through the collectives)
+            sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * F * 6]
             packed = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
             parts = torch.split(packed, sizes)
-            grads = (parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(F), parts[3].view(B, P, 3),
-                     parts[4].view(B, F), parts[5].view(B, F, 3, 2))
+            grads = (parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(F), parts[4].view(B, P, 3),
+                     parts[3].view(B, F), parts[5].view(B, F, 3, 2))
             grads[0]._dm2_packed = packed
         else:
             f = self.fwd
@@ -214,7 +215,8 @@ class BandShardedOp:
         return fn(self.fwd[7], B, F)
 
     def backward_leaves(self, dL_dcolor_band, dL_ddepth_band, prep_inputs, group=None, prep_backward=None, exchange="dense"):
-        """Band gradients -> gradients of the leaves, summed over ranks with ONE all-reduce of 24P + 4F + 4BF bytes.
+        """Band gradients -> gradients of the leaves, summed over ranks by a dense all-reduce of 24P + 4F + 4BF bytes
+        (in two parts: colour / opacity / intensity start while the host-prep backward still runs, dverts follows).
 
         ``prep_inputs`` = (verts, faces, mv, proj, width, height) of the host prep that produced ``verts_ndc`` /
         ``aa_face_verts`` (mv / proj of the rendered cameras, FULL image size).  Returns
@@ -227,27 +229,37 @@ class BandShardedOp:
         dverts, dcolor, dopacity, dndc, dintense, daa = g
         verts, faces, mv, proj, width, height = prep_inputs
         pb = prep_backward or self._C.prepare_faces_backward
+        dense = not (exchange == "sparse" and self.world_size > 1)
+        packed = getattr(dverts, "_dm2_packed", None)
+        n_v, n_rest = dverts.numel(), dcolor.numel() + dopacity.numel() + dintense.numel()
+        es = dverts.element_size()
+        leaf_span = (packed is not None and packed.numel() >= n_v + n_rest and dverts.data_ptr() == packed.data_ptr()
+                     and dcolor.data_ptr() == packed.data_ptr() + es * n_v
+                     and dopacity.data_ptr() == dcolor.data_ptr() + es * dcolor.numel()
+                     and dintense.data_ptr() == dopacity.data_ptr() + es * dopacity.numel())
+        early = None
+        if dense and leaf_span and self.world_size > 1:
+            # the op's own gradients of colour / opacity / intensity are final: their all-reduce starts now and runs while
+            # the host-prep backward below adds its share to dverts
+            early = dist.all_reduce(packed[n_v:n_v + n_rest], op=dist.ReduceOp.SUM, group=group, async_op=True)
         dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
-        if exchange == "sparse" and self.world_size > 1:
+        if not dense:
             touched = self.touched_faces()
             if touched is None:      # backend without the scratch accessor: any face or vertex row that is not exactly zero
                 fl = faces.long()
                 touched = (dopacity != 0) | (dintense != 0).any(dim=0) | (dverts[fl] != 0).any(dim=2).any(dim=1) | \
                           (dcolor[fl] != 0).any(dim=2).any(dim=1)
             return reduce_leaves_sparse(dverts, dcolor, dopacity, dintense, faces, touched, group)
-        packed = getattr(dverts, "_dm2_packed", None)
-        n_leaf = dverts.numel() + dcolor.numel() + dopacity.numel()
-        if packed is not None and packed.numel() >= n_leaf + dintense.numel() and dndc.numel() >= dintense.numel():
-            # [dverts | dverts_color | dfaces_opacity] are contiguous at the head of the packed buffer; park
-            # dfaces_intense right behind them (over the no longer needed head of dverts_ndc) -> one contiguous span
-            span = packed[: n_leaf + dintense.numel()]
-            span[n_leaf:].copy_(dintense.reshape(-1))
-            dintense = span[n_leaf:].view(dintense.shape)
-        else:
-            span = torch.cat([dverts.reshape(-1), dcolor.reshape(-1), dopacity.reshape(-1), dintense.reshape(-1)])
-            o1, o2, o3 = dverts.numel(), dverts.numel() + dcolor.numel(), n_leaf
-            dverts, dcolor, dopacity, dintense = (span[:o1].view(dverts.shape), span[o1:o2].view(dcolor.shape),
-                                                  span[o2:o3].view(dopacity.shape), span[o3:].view(dintense.shape))
+        if leaf_span:
+            # [dverts | dverts_color | dfaces_opacity | dfaces_intense] head the backward's packed buffer (_C.render_backward_cuda)
+            if self.world_size > 1:
+                dist.all_reduce(packed[:n_v], op=dist.ReduceOp.SUM, group=group)
+                early.wait()
+            return dverts, dcolor, dopacity, dintense
+        span = torch.cat([dverts.reshape(-1), dcolor.reshape(-1), dopacity.reshape(-1), dintense.reshape(-1)])
+        o1, o2, o3 = n_v, n_v + dcolor.numel(), n_v + dcolor.numel() + dopacity.numel()
+        dverts, dcolor, dopacity, dintense = (span[:o1].view(dverts.shape), span[o1:o2].view(dcolor.shape),
+                                              span[o2:o3].view(dopacity.shape), span[o3:].view(dintense.shape))
         if self.world_size > 1:
             dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
         return dverts, dcolor, dopacity, dintense

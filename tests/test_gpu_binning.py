@@ -85,3 +85,28 @@ def test_empty_and_untouched_tiles():
     far[8] = far[8] + 10.0          # every vertex behind the far plane: culled (forward.cu:71)
     R0, ranges0, _ = _lists(far)
     assert R0 == 0 and not ranges0.any()
+
+
+def test_small_and_large_faces_share_tiles():
+    """Faces of at most four tiles take their place in the tile segment during the plan, larger ones are counted apart and
+    placed behind them through a cursor (dm2_binning.hip): a scene that mixes both in every tile, two views."""
+    W, H, cams = 128, 96, 2
+    small = scenes.triangle_soup(W, H, 3000, scenes.SEED_BASE + 811, num_cams=cams, shared_verts=False, depth_complexity=3.0)
+    large = scenes.triangle_soup(W, H, 60, scenes.SEED_BASE + 812, num_cams=cams, shared_verts=False, depth_complexity=40.0)
+    sc = small
+    P0 = small.verts.shape[0]
+    sc.verts = torch.cat([small.verts, large.verts]); sc.verts_color = torch.cat([small.verts_color, large.verts_color])
+    # interleave: the large faces sit between the small ones in face order
+    f_all = torch.cat([small.faces, large.faces + P0]); perm = torch.randperm(f_all.shape[0], generator=torch.Generator().manual_seed(3))
+    sc.faces = f_all[perm].contiguous()
+    sc.faces_opacity = torch.cat([small.faces_opacity, large.faces_opacity])[perm].contiguous()
+    sc.faces_intense = torch.cat([small.faces_intense, large.faces_intense], dim=1)[:, perm].contiguous()
+    args = capture_forward_args(sc, [0, 1], [[0, 0]] * 2, W, H, 0.0, 0)[0]
+    R_ref, ranges_ref, flist_ref = _oracle_lists(args)
+    from oracle import cpu as orc
+    a = [x.numpy() if torch.is_tensor(x) else x for x in args]
+    tt = orc.Binning(a[8].shape[0], a[4].shape[0], a[5].shape[0], W, H, a[1], a[5], a[8], a[9]).tiles_touched
+    assert (tt > 4).sum() >= 40 and ((tt > 0) & (tt <= 4)).sum() >= 2000, "the scene must mix both kinds of faces"
+    for legacy in (False, True):
+        R, ranges, flist = _lists(args, legacy)
+        assert R == R_ref and np.array_equal(ranges, ranges_ref) and np.array_equal(flist, flist_ref), legacy

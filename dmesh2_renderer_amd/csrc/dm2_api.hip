@@ -35,27 +35,54 @@ int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-struct PinnedWord {     // per-thread pinned staging words + event for the plan's read-back
-    uint32_t* p = nullptr;
+struct PinnedWord {     // per-thread mapped host words for the plan's read-back
+    uint32_t* p = nullptr;      // host view: [0] num_rendered [1] longest tile list [2] sequence word
+    uint32_t* dp = nullptr;     // device view of the same memory
+    uint32_t seq = 0;
     hipEvent_t ev = nullptr;
     ~PinnedWord() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
 };
 thread_local PinnedWord g_pin;
 
-// (num_rendered, entries of the longest tile list) of the plan that just ran on `st`: the one host read-back of a forward.
-// Two halves (an event, not a stream synchronise: work a caller enqueues on the stream afterwards is not waited for).
-int plan_meta_enqueue(const uint32_t* plan_meta, hipStream_t st) {
-    if (!g_pin.p) DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocDefault));
+// (num_rendered, entries of the longest tile list) of a plan: the one host read-back of a forward.  The plan's last kernel
+// stores them into mapped host memory and then a sequence word; the host polls that word (microseconds instead of the
+// ~30 us of a copy command + event).  Should the word not show up in time (a platform that delays such stores until the
+// kernel has retired), the classical route takes over: an event behind a device-to-host copy of the device-side words.
+int plan_meta_prepare(uint32_t** host_meta_dev, uint32_t* seq) {
+    if (!g_pin.p) {
+        DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocMapped));
+        g_pin.p[0] = g_pin.p[1] = g_pin.p[2] = 0u;
+        void* dp = nullptr;
+        DM2_HIP(hipHostGetDevicePointer(&dp, g_pin.p, 0));
+        g_pin.dp = (uint32_t*)dp;
+    }
     if (!g_pin.ev) DM2_HIP(hipEventCreateWithFlags(&g_pin.ev, hipEventDisableTiming));
-    DM2_HIP(hipMemcpyAsync(g_pin.p, plan_meta, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    DM2_HIP(hipEventRecord(g_pin.ev, st));
+    g_pin.seq = g_pin.seq + 1u ? g_pin.seq + 1u : 1u;                      // never 0: the words start out as 0
+    *host_meta_dev = g_pin.dp; *seq = g_pin.seq;
     return 0;
 }
-int plan_meta_wait(int64_t* num_rendered, int64_t* max_tile_entries) {
-    DM2_HIP(hipEventSynchronize(g_pin.ev));
-    *num_rendered = (int64_t)g_pin.p[0];
-    *max_tile_entries = (int64_t)g_pin.p[1];
-    if (g_pin.p[1] == 0xFFFFFFFFu) { *num_rendered = 0; *max_tile_entries = 0; return fail("more than 2^31 - 1 (tile, face) pairs: render smaller patches"); }
+int plan_meta_wait(const uint32_t* plan_meta, hipStream_t st, int64_t* num_rendered, int64_t* max_tile_entries) {
+    DM2_HIP(hipEventRecord(g_pin.ev, st));                                 // (also tells whether the plan has retired)
+    volatile uint32_t* hp = g_pin.p;
+    uint32_t r = 0, longest = 0;
+    bool seen = false;
+    for (long spin = 0; ; spin++) {
+        if (__atomic_load_n(&hp[2], __ATOMIC_ACQUIRE) == g_pin.seq) { r = hp[0]; longest = hp[1]; seen = true; break; }
+        if ((spin & 1023) == 1023 && hipEventQuery(g_pin.ev) != hipErrorNotReady) {
+            // the plan's kernels are done (or the stream is in error): the stores are visible now, or they never will be
+            if (__atomic_load_n(&hp[2], __ATOMIC_ACQUIRE) == g_pin.seq) { r = hp[0]; longest = hp[1]; seen = true; }
+            break;
+        }
+    }
+    if (!seen) {
+        uint32_t tmp[2] = {0u, 0u};
+        DM2_HIP(hipMemcpyAsync(tmp, plan_meta, sizeof(tmp), hipMemcpyDeviceToHost, st));
+        DM2_HIP(hipStreamSynchronize(st));
+        r = tmp[0]; longest = tmp[1];
+    }
+    *num_rendered = (int64_t)r;
+    *max_tile_entries = (int64_t)longest;
+    if (longest == 0xFFFFFFFFu) { *num_rendered = 0; *max_tile_entries = 0; return fail("more than 2^31 - 1 (tile, face) pairs: render smaller patches"); }
     return 0;
 }
 
@@ -166,10 +193,12 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
     if (d->P == 0 || BF == 0 || Tn == 0) return 0;                       // render.cu:149
     if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
     dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
-    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d, st));
+    uint32_t* host_meta = nullptr; uint32_t seq = 0;
+    if (plan_meta_prepare(&host_meta, &seq)) return 1;
+    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d,
+                                        host_meta, seq, st));
     DM2_HIP(hipGetLastError());
-    if (plan_meta_enqueue(fs.plan_meta, st)) return 1;
-    return plan_meta_wait(num_rendered, max_tile_entries);
+    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
 
 int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
@@ -244,10 +273,12 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn) > face_bytes) return fail("face scratch too small");
     dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), false);
     // patch_min = 0 (renderer.cu:557-558): a null patch_min means "all zeros"
-    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr, st));
+    uint32_t* host_meta = nullptr; uint32_t seq = 0;
+    if (plan_meta_prepare(&host_meta, &seq)) return 1;
+    DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr,
+                                        host_meta, seq, st));
     DM2_HIP(hipGetLastError());
-    if (plan_meta_enqueue(fs.plan_meta, st)) return 1;
-    return plan_meta_wait(num_rendered, max_tile_entries);
+    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
 
 int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,

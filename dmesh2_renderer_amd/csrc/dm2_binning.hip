@@ -182,7 +182,7 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
 // kernel runs on, against 4.)
 __global__ void __launch_bounds__(1024)
 k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, uint32_t* __restrict__ start,
-            uint32_t* __restrict__ meta) {
+            uint32_t* __restrict__ meta, uint32_t* host_meta, uint32_t host_seq) {
     constexpr int RUN = 8, ROUND = 1024 * RUN;
     __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
@@ -222,7 +222,16 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     }
     if (mx) atomicMax(&s_max, mx);
     __syncthreads();
-    if (tid == 0) { meta[0] = carry; meta[1] = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max; }      // (per-round totals stay below 2^32: 8192 tiles)
+    if (tid == 0) {
+        const uint32_t longest = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max;      // (per-round totals stay below 2^32: 8192 tiles)
+        meta[0] = carry; meta[1] = longest;
+        if (host_meta) {
+            // the two numbers the host waits for, straight into its mapped memory, then the sequence word it polls: no copy
+            // command, no event -- the host learns them microseconds after this store instead of ~30 us later
+            host_meta[0] = carry; host_meta[1] = longest;
+            __hip_atomic_store(&host_meta[2], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count): entries of faces
@@ -423,7 +432,7 @@ size_t sort_temp_bytes(int64_t R, int64_t Tn) {
 
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  hipStream_t st) {
+                                  uint32_t* host_meta, uint32_t host_seq, hipStream_t st) {
     const int64_t BF = (int64_t)B * F;
     if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -438,7 +447,7 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta, host_meta, host_seq);
     return hipSuccess;
 }
 

@@ -122,9 +122,11 @@ unsigned sort_end_bit(int64_t Tn);
 
 // plan: preprocess (forward.cu:16-108) + entries per tile + their scan -> fs.plan_meta = (num_rendered, longest list)
 // pack != nullptr: also write the packed face records fs.recs from the op's inputs
+// host_meta != nullptr: DEVICE pointer to three words of mapped host memory: (num_rendered, longest list, host_seq) are
+// stored there by the last kernel, the sequence word last (system-scope release)
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  hipStream_t st);
+                                  uint32_t* host_meta, uint32_t host_seq, hipStream_t st);
 // run: the sorted per-tile lists (renderer.cu:185-219): face_list ordered by (tile, depth key, emission order) + ranges.
 // key depth = depths or min_depths.  max_tile_entries (from the plan) picks the method: per-tile sorts in LDS, or -- lists
 // beyond TILE_SORT_MAX entries, or legacy = true -- the reference's way, one global stable radix sort.

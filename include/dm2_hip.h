@@ -20,7 +20,8 @@
  *
  * All pointers are DEVICE pointers to contiguous row-major arrays unless noted.
  * All functions enqueue on `stream` (a hipStream_t passed as void*; NULL = the
- * null stream); only the plan functions wait for the GPU (for one 8-byte D2H read).
+ * null stream); only the plan functions wait for the GPU: for two words their last kernel stores
+ * into mapped host memory (polled; a copy + event takes over where such stores are not seen in time).
  * Return value: 0 on success, non-zero on error with a message available from
  * dm2_last_error() (thread local).  The library keeps no global state besides
  * a per-thread pinned staging word.

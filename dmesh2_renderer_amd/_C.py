@@ -34,6 +34,7 @@ SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
 _flags = 0
+_bin_hint: dict = {}      # (device, B, W, H, F) -> bytes of binning scratch that held the last forward of that shape
 
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 
@@ -76,6 +77,8 @@ EXPORTS = {
     "dm2_scratch_bytes": (_sz, [ctypes.c_int, _i64, _i64]),
     "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dm2_forward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp,
+                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
@@ -330,13 +333,26 @@ def render_forward_cuda(*args):
         face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 2 * Tn + 1))
         img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_IMAGE, N, Tn))
         nr, longest = _i64(0), _i64(0)
-        if lib.dm2_forward_plan(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), st, ctypes.byref(nr), ctypes.byref(longest)):
-            raise _err(lib, "render_forward_cuda (plan)")
+        # the binning scratch is sized from the last call on this device (+ 25 %): when it fits -- every step of a training
+        # loop but the first -- plan and run are one C call and the GPU does not wait for Python in between
+        key = (dev.index, B, W, H, F)
+        bin_buf = _bytes(dev, _bin_hint.get(key, 0))
+        rc = lib.dm2_forward(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(), _ptr(img_buf), img_buf.numel(),
+                             _ptr(color), _ptr(depth), _ptr(tri_cnt), st, ctypes.byref(nr), ctypes.byref(longest))
+        if rc not in (0, 2):
+            raise _err(lib, "render_forward_cuda")
         R = int(nr.value)
-        bin_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn))
-        if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
-                               _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st):
-            raise _err(lib, "render_forward_cuda (run)")
+        need = lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn)
+        if rc == 2:
+            bin_buf = _bytes(dev, need + need // 4)
+            if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
+                                   _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st):
+                raise _err(lib, "render_forward_cuda (run)")
+        hint = _bin_hint.get(key, 0)
+        if need > hint or 2 * (need + need // 4) < hint:
+            if len(_bin_hint) > 64:
+                _bin_hint.clear()
+            _bin_hint[key] = need + need // 4
     return R, color, depth, oarea, tri_id, tri_cnt, doarea, face_buf, bin_buf, img_buf
 
 

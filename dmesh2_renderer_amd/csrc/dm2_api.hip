@@ -228,6 +228,16 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_
     return 0;
 }
 
+int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* binning_scratch, size_t binning_bytes,
+                void* image_scratch, size_t image_bytes, float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream,
+                int64_t* num_rendered, int64_t* max_tile_entries) {
+    if (dm2_forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries)) return 1;
+    const int64_t Tn = tiles_of(d->B, d->W, d->H);
+    if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) > binning_bytes) return 2;      // plan done; allocate, then dm2_forward_run
+    return dm2_forward_run(d, *num_rendered, *max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes,
+                           image_scratch, image_bytes, out_color, out_depth, out_tri_cnt, stream);
+}
+
 int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL_dout_color, const float* dL_dout_depth,
                  const void* face_scratch, size_t face_bytes, const void* binning_scratch, size_t binning_bytes,
                  const void* image_scratch, size_t image_bytes,

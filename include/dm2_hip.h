@@ -128,6 +128,17 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_
                     void* image_scratch, size_t image_bytes,
                     float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream);
 
+/* dm2_forward_plan + dm2_forward_run in ONE call for a caller that already holds a binning scratch of plausible size (a
+ * training loop: last frame's size plus headroom): the run step is enqueued straight from the plan's read-back, without
+ * the round trip through the caller that otherwise leaves the GPU idle (~15 us of a 25-us gap through Python).
+ * Returns 0 (rendered; *num_rendered / *max_tile_entries set), 2 when binning_bytes is smaller than
+ * dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, B*tiles) -- the plan is done and nothing else: allocate and
+ * call dm2_forward_run -- or 1 on error.  A larger-than-needed binning scratch is fine, also for dm2_backward. */
+int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
+                void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream,
+                int64_t* num_rendered, int64_t* max_tile_entries);
+
 /* Gradients (BACKWARD::renderCUDA backward.cu:17-532).  The six outputs must be
  * zero-filled by the caller (the reference's zeros_like, render.cu:313-318):
  * dL_dverts (P,3), dL_dverts_color (P,3), dL_dfaces_opacity (F),

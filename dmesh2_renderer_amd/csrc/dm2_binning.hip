@@ -34,6 +34,17 @@
 
 namespace dm2 {
 
+// Clears n 32-bit words.  A kernel of the library's own instead of hipMemsetAsync: the runtime's fill is a blit with a
+// barrier packet on either side (kernel-trace gaps of 10 us behind a compute kernel, 4 us in front of the next one);
+// a plain dispatch follows and is followed back to back.
+__global__ void __launch_bounds__(256) k_zero_words(uint32_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static void launch_zero_words(void* p, int64_t n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, n);
+}
+
 // One count per active lane into cnt[STRIDE * t].  RANK: also returns a place per lane, as its own atomicAdd(.., 1) would.
 // A global atomic costs the same ~60 ps per LANE whether or not lanes collide (1.6 M of them: 0.08 ms), so lanes of a wave
 // that hit the same tile -- neighbouring faces of a mesh, a tet lattice -- are grouped first: the group's first lane adds the
@@ -440,8 +451,7 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
     if (Tn == 0) return hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
-    hipError_t e = hipMemsetAsync(fs.tile_cnt, 0, (size_t)(2 * Tn) * sizeof(uint32_t), st);   // (k_tile_scan writes plan_meta)
-    if (e != hipSuccess) return e;
+    launch_zero_words(fs.tile_cnt, 2 * Tn, st);                            // (k_tile_scan writes plan_meta)
     if (pack && fs.recs)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
     else
@@ -455,8 +465,9 @@ hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_ti
                            FaceState fs, BinningState bs, uint2* ranges, hipStream_t st) {
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)Tn * sizeof(uint2), st);           // renderer.cu:211
-    if (e != hipSuccess || R <= 0) return e;
+    launch_zero_words(ranges, 2 * Tn, st);                                 // renderer.cu:211
+    hipError_t e = hipSuccess;
+    if (R <= 0) return e;
     const int64_t BF = (int64_t)B * F;
     if (!legacy && max_tile_entries <= TILE_SORT_MAX) {
         {

@@ -183,8 +183,8 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
     return total;
 }
 
-int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
-                     int64_t* max_tile_entries) {
+static int forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
+                        int64_t* max_tile_entries, uint2* ranges_to_clear) {
     if (check_render_desc(d)) return 1;
     if (!num_rendered || !max_tile_entries) return fail("num_rendered / max_tile_entries is null");
     hipStream_t st = (hipStream_t)stream;
@@ -196,14 +196,19 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
     uint32_t* host_meta = nullptr; uint32_t seq = 0;
     if (plan_meta_prepare(&host_meta, &seq)) return 1;
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d,
-                                        host_meta, seq, st));
+                                        host_meta, seq, ranges_to_clear, st));
     DM2_HIP(hipGetLastError());
     return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
 
-int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
-                    void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
-                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream) {
+int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
+                     int64_t* max_tile_entries) {
+    return forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, nullptr);
+}
+
+static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
+                       void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                       float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream, bool ranges_cleared) {
     if (check_render_desc(d)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int64_t BF = (int64_t)d->B * d->F, N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
@@ -219,7 +224,7 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
         is.face_recs = fs.recs;
         DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
-                                     fs.depths, fs, bs, is.ranges, st));   // renderer.cu:192
+                                     fs.depths, fs, bs, is.ranges, ranges_cleared, st));   // renderer.cu:192
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
@@ -228,14 +233,26 @@ int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_
     return 0;
 }
 
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
+                    void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
+                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream) {
+    return forward_run(d, num_rendered, max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes, image_scratch,
+                       image_bytes, out_color, out_depth, out_tri_cnt, stream, false);
+}
+
 int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* binning_scratch, size_t binning_bytes,
                 void* image_scratch, size_t image_bytes, float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream,
                 int64_t* num_rendered, int64_t* max_tile_entries) {
-    if (dm2_forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries)) return 1;
-    const int64_t Tn = tiles_of(d->B, d->W, d->H);
+    if (check_render_desc(d)) return 1;
+    const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
+    // the image scratch is at hand already: the plan's last kernel clears the tile ranges, one launch less in the run step
+    uint2* ranges = nullptr;
+    if (N > 0 && image_scratch && dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) <= image_bytes) ranges = dm2::ImageState::carve(image_scratch, N, Tn).ranges;
+    if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, ranges)) return 1;
+    const bool planned = d->P != 0 && (int64_t)d->B * d->F != 0 && Tn != 0;     // (otherwise no plan kernel ran)
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) > binning_bytes) return 2;      // plan done; allocate, then dm2_forward_run
-    return dm2_forward_run(d, *num_rendered, *max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes,
-                           image_scratch, image_bytes, out_color, out_depth, out_tri_cnt, stream);
+    return forward_run(d, *num_rendered, *max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes,
+                       image_scratch, image_bytes, out_color, out_depth, out_tri_cnt, stream, planned && ranges != nullptr);
 }
 
 int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL_dout_color, const float* dL_dout_depth,
@@ -286,7 +303,7 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     uint32_t* host_meta = nullptr; uint32_t seq = 0;
     if (plan_meta_prepare(&host_meta, &seq)) return 1;
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr,
-                                        host_meta, seq, st));
+                                        host_meta, seq, nullptr, st));
     DM2_HIP(hipGetLastError());
     return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
 }
@@ -309,7 +326,7 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_t
         fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), false);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
         DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
-                                     fs.min_depths, fs, bs, ls.ranges, st));   // renderer.cu:603
+                                     fs.min_depths, fs, bs, ls.ranges, false, st));   // renderer.cu:603
     } else {
         DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }

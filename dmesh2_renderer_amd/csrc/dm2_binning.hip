@@ -193,7 +193,7 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
 // kernel runs on, against 4.)
 __global__ void __launch_bounds__(1024)
 k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, uint32_t* __restrict__ start,
-            uint32_t* __restrict__ meta, uint32_t* host_meta, uint32_t host_seq) {
+            uint32_t* __restrict__ meta, uint32_t* host_meta, uint32_t host_seq, uint2* __restrict__ ranges_to_clear) {
     constexpr int RUN = 8, ROUND = 1024 * RUN;
     __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
@@ -227,7 +227,10 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
         for (int k = 0; k < RUN; k++) {
             const int i = k * 1024 + tid;
             const int64_t t = base + i;
-            if (t < Tn) start[t] = s_c[i + (i >> 5)];
+            if (t < Tn) {
+                start[t] = s_c[i + (i >> 5)];
+                if (ranges_to_clear) ranges_to_clear[t] = make_uint2(0u, 0u);     // (the run step's fill cursors / renderer.cu:211)
+            }
         }
         __syncthreads();                                   // s_c and s_w are rewritten by the next round
     }
@@ -422,10 +425,15 @@ static uint32_t higher_msb(uint32_t n) {
     return msb;
 }
 
+// (rocPRIM's size queries resolve a device configuration every time they are asked: a few microseconds each, and a forward
+// asks half a dozen times between the plan's read-back and the run step's first launch -- the last answers are kept)
 size_t scan_temp_bytes(int64_t BF) {
+    thread_local int64_t last_bf = -1; thread_local size_t last_bytes = 0;
+    if (BF == last_bf) return last_bytes;
     size_t bytes = 0;
     uint32_t* p = nullptr;
     (void)rocprim::inclusive_scan(nullptr, bytes, p, p, (size_t)(BF > 0 ? BF : 1), rocprim::plus<uint32_t>());
+    last_bf = BF; last_bytes = bytes;
     return bytes;
 }
 
@@ -435,15 +443,18 @@ unsigned sort_end_bit(int64_t Tn) {
 }
 
 size_t sort_temp_bytes(int64_t R, int64_t Tn) {
+    thread_local int64_t last_r = -1, last_tn = -1; thread_local size_t last_bytes = 0;
+    if (R == last_r && Tn == last_tn) return last_bytes;
     size_t bytes = 0;
     uint64_t* k = nullptr; uint32_t* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(R > 0 ? R : 1), 0u, sort_end_bit(Tn));
+    last_r = R; last_tn = Tn; last_bytes = bytes;
     return bytes;
 }
 
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  uint32_t* host_meta, uint32_t host_seq, hipStream_t st) {
+                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, hipStream_t st) {
     const int64_t BF = (int64_t)B * F;
     if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -457,15 +468,16 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta, host_meta, host_seq);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta, host_meta, host_seq,
+                       ranges_to_clear);
     return hipSuccess;
 }
 
 hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
-                           FaceState fs, BinningState bs, uint2* ranges, hipStream_t st) {
+                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, hipStream_t st) {
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
-    launch_zero_words(ranges, 2 * Tn, st);                                 // renderer.cu:211
+    if (!ranges_cleared) launch_zero_words(ranges, 2 * Tn, st);            // renderer.cu:211 (or done by the plan's last kernel)
     hipError_t e = hipSuccess;
     if (R <= 0) return e;
     const int64_t BF = (int64_t)B * F;

@@ -124,15 +124,17 @@ unsigned sort_end_bit(int64_t Tn);
 // pack != nullptr: also write the packed face records fs.recs from the op's inputs
 // host_meta != nullptr: DEVICE pointer to three words of mapped host memory: (num_rendered, longest list, host_seq) are
 // stored there by the last kernel, the sequence word last (system-scope release)
+// ranges_to_clear != nullptr: the last kernel also zeroes these Tn tile ranges (what the run step would do first)
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  uint32_t* host_meta, uint32_t host_seq, hipStream_t st);
+                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, hipStream_t st);
 // run: the sorted per-tile lists (renderer.cu:185-219): face_list ordered by (tile, depth key, emission order) + ranges.
 // key depth = depths or min_depths.  max_tile_entries (from the plan) picks the method: per-tile sorts in LDS, or -- lists
 // beyond TILE_SORT_MAX entries, or legacy = true -- the reference's way, one global stable radix sort.
 constexpr int64_t TILE_SORT_MAX = 32768;
+// ranges_cleared: the plan's last kernel has already zeroed `ranges` (launch_preprocess_scan's ranges_to_clear)
 hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
-                           FaceState fs, BinningState bs, uint2* ranges, hipStream_t st);
+                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, hipStream_t st);
 
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,

@@ -30,6 +30,7 @@ DM2_FLAG_CORRECTED_DV = 1
 DM2_FLAG_LEGACY_KERNELS = 2
 DM2_FLAG_NO_BACKWARD = 4
 DM2_FLAG_ANALYTIC_RAYS = 8
+DM2_FLAG_AA_GRAD_TO_VERTS = 16
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS = 0, 1, 2, 3, 4
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
@@ -288,6 +289,23 @@ class analytic_rays:
         _tls.analytic = self.old
 
 
+class aa_grad_to_verts:
+    """``with _C.aa_grad_to_verts(True): _C.render_backward_cuda(...)`` -- the sixth gradient is not dL/d(aa_face_verts)
+    (B,F,3,2) but that gradient already scattered to the vertices the corners belong to, (B,P,2): the gradient of
+    ``verts_image`` through the reordered copy (DM2_FLAG_AA_GRAD_TO_VERTS).  For a caller that owns the host prep as well
+    (Renderer with the fused prep).  A side channel like ``forward_only``: the 31-argument signature stays the reference's."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = getattr(_tls, "aa_to_verts", False)
+        _tls.aa_to_verts = self.on
+
+    def __exit__(self, *exc):
+        _tls.aa_to_verts = self.old
+
+
 def _analytic(B, dev):
     a = getattr(_tls, "analytic", None)
     if a is None:
@@ -376,11 +394,15 @@ def render_backward_cuda(*args):
     f32 = torch.float32
     # physical order: the gradients of the LEAVES first ([dverts | dverts_color | dfaces_opacity | dfaces_intense], one
     # contiguous span for a multi-GPU caller), then the two intermediates of the host prep (dverts_ndc, daa_face_verts)
-    sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * F * 6]
+    to_verts = bool(getattr(_tls, "aa_to_verts", False))
+    if to_verts:
+        d.flags |= DM2_FLAG_AA_GRAD_TO_VERTS
+    sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * P * 2 if to_verts else B * F * 6]
     packed = torch.zeros((sum(sizes),), dtype=f32, device=dev)          # render.cu:313-318 zeros_like x6
     parts = torch.split(packed, sizes)
     g_verts = parts[0].view(P, 3); g_color = parts[1].view(P, 3); g_opac = parts[2].view(F)
-    g_int = parts[3].view(B, F); g_ndc = parts[4].view(B, P, 3); g_aa = parts[5].view(B, F, 3, 2)
+    g_int = parts[3].view(B, F); g_ndc = parts[4].view(B, P, 3)
+    g_aa = parts[5].view(B, P, 2) if to_verts else parts[5].view(B, F, 3, 2)
     if F != 0 and P != 0 and num_rendered > 0 and B * H * W > 0:
         if tuple(dL_dcolor.shape) != (B, H, W, 3) or tuple(dL_ddepth.shape) != (B, H, W):
             raise RuntimeError("dL_dout_color / dL_dout_depth must have dimensions (B, H, W, 3) / (B, H, W)")

@@ -29,6 +29,7 @@ __all__ = ["RenderFunction", "Renderer", "LayeredRenderer", "Triangles"]
 # GEMM's in the last bit, well inside the 1e-5 of the port's tolerance); DM2_FUSED_PREP=0 or Renderer(fused_prep=False)
 # selects the reference-shaped torch ops.
 _FUSED_PREP_DEFAULT = os.environ.get("DM2_FUSED_PREP", "1") != "0"
+_FUSED_AA_GRAD = os.environ.get("DM2_FUSED_AA_GRAD", "1") != "0"
 _W_EPS = 1e-4   # |w| clamp of the projection, sign kept (reference __init__.py:254-255)
 
 
@@ -56,6 +57,9 @@ class RenderFunction(torch.autograd.Function):
         # analytic rays (Renderer(analytic_rays=True)): the camera block rides along in the thread-local side channel and is
         # kept for the backward
         ctx.analytic = getattr(_C._tls, "analytic", None)
+        # fused host prep: the AA-corner gradients come back already scattered to the vertices' image coordinates
+        # (input 9, verts_image) instead of as dL/d(aa_face_verts) (input 12) -- see _C.aa_grad_to_verts
+        ctx.aa_to_verts = bool(getattr(_C._tls, "aa_to_verts", False))
         try:
             with _C.forward_only(not any(ctx.needs_input_grad)):
                 out = _C.render_forward_cuda(*inputs)
@@ -84,7 +88,7 @@ class RenderFunction(torch.autograd.Function):
         oarea, tri_id, tri_cnt, doarea, face_buf, binning_buf, image_buf = saved[ctx.n_tensor_in:]
         try:
             ana = ctx.analytic
-            with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))):
+            with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))), _C.aa_grad_to_verts(ctx.aa_to_verts):
                 grads = _C.render_backward_cuda(
                     ctx.num_rendered, *inputs, grad_out_color, grad_out_depth,
                     face_buf, binning_buf, image_buf, oarea, tri_id, tri_cnt, doarea)
@@ -95,6 +99,8 @@ class RenderFunction(torch.autograd.Function):
         result: list = [None] * RenderFunction.N_INPUTS
         for slot, g in zip(RenderFunction._GRAD_SLOTS, grads):
             result[slot] = g
+        if ctx.aa_to_verts:
+            result[9], result[12] = grads[5], None          # (B,P,2): the gradient of verts_image, not of aa_face_verts
         return tuple(result)
 
 
@@ -228,11 +234,15 @@ class Renderer(torch.nn.Module):
             from . import prep
             (verts_ndc, verts_image, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c) = prep.prepare(
                 verts.to(f32), faces.to(torch.int32), mv.to(f32), proj.to(f32), self.width, self.height)
-            color, depth = RenderFunction.apply(
-                background.to(f32), batch_patch_min.to(torch.int32), patch_width, patch_height,
-                verts.to(f32), faces.to(torch.int32), verts_color.to(f32), faces_opacity.to(f32),
-                verts_ndc, verts_image, faces_intense.to(f32), aa_temperature,
-                aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, self.aa_grad_buffer_size, ray_o.to(f32), ray_d.to(f32))
+            # the fused prep owns both ends of aa_face_verts: the op hands its corner gradients back per VERTEX (as the
+            # gradient of verts_image) and prepare_faces_backward needs no (B,F,3,2) scatter pass (DM2_FUSED_AA_GRAD=0: the
+            # reference's route through dL/d(aa_face_verts))
+            with _C.aa_grad_to_verts(_FUSED_AA_GRAD and verts_image.requires_grad):
+                color, depth = RenderFunction.apply(
+                    background.to(f32), batch_patch_min.to(torch.int32), patch_width, patch_height,
+                    verts.to(f32), faces.to(torch.int32), verts_color.to(f32), faces_opacity.to(f32),
+                    verts_ndc, verts_image, faces_intense.to(f32), aa_temperature,
+                    aa_v, aa_e, aa_z, aa_r, aa_n, aa_c, self.aa_grad_buffer_size, ray_o.to(f32), ray_d.to(f32))
             return color, 1.0 - (depth + 1.0) / 2.0
         verts_ndc, verts_image = self.compute_verts_ndc_image(verts, mv, proj)
 

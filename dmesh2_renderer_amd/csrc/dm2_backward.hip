@@ -216,6 +216,11 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
                 else if (comp < A_OP) dst = dL_dverts_ndc + ((int64_t)b * d.P + fc.vid[comp - A_DZ]) * 3 + 2;
                 else if (comp == A_OP) dst = dL_dfaces_opacity + fc.face_id;
                 else if (comp == A_IN) dst = dL_dfaces_intense + (int64_t)b * d.F + fc.face_id;
+                else if (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) {                  // corner -> the vertex the CCW reorder took it from
+                    const int c = (comp - A_AA) >> 1;
+                    const bool flip = (fc.aa.zmask >> 8) & 1u;
+                    dst = dL_daa_face_verts + ((int64_t)b * d.P + fc.vid[c == 0 ? 0 : (flip ? 3 - c : c)]) * 2 + ((comp - A_AA) & 1);
+                }
                 else dst = dL_daa_face_verts + ((int64_t)b * d.F + fc.face_id) * 6 + (comp - A_AA);
                 atomicAdd(dst, val);
             }

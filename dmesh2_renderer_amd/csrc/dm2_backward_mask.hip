@@ -112,7 +112,7 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
     if (tid == 0) s_max_lc = 0;
     if (tid < M_N) fill_flush_table(tid, b, d.P, d.F, dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense,
-                                    dL_daa_face_verts, s_fl_base, s_fl_sel);
+                                    dL_daa_face_verts, s_fl_base, s_fl_sel, (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) != 0);
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_lc, last_contributor);
     __syncthreads();
@@ -458,11 +458,13 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         const int comp = tid & 31;
         if (comp < M_N) {
             float* const basep = s_fl_base[comp];                                 // (per-component table, filled in the prologue)
-            const int sel = s_fl_sel[comp] & 3, mult = s_fl_sel[comp] >> 2;
+            const int entry = s_fl_sel[comp];
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
                 float* a = acc + e * BM_ACC;
                 const float flag = a[M_FLAG];                                     // (the 32 lanes of an entry sit in one wave)
                 const float val = a[comp];
+                int sel, mult;
+                flush_id_and_mult(entry, recs[e].aa.zmask, sel, mult);
                 const int id = (&recs[e].face_id)[sel];
                 if (flag != 0.f) {
                     a[comp] = 0.f;                                                // ready for the next chunk

@@ -37,10 +37,18 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {
 
 // Flush table: component comp of an accumulator row goes to  base + 4 * (id * mult),  id one of the record's
 // (face_id, vid[0..2]) -- filled once per block by the lanes comp < M_N.
+// aa_to_verts (DM2_FLAG_AA_GRAD_TO_VERTS): dL_daa_face_verts is a (B,P,2) array and corner c of the record goes to the
+// vertex the CCW reorder took it from: entry = corner | 0x80, resolved per record by flush_id_and_mult.
 template <class SelT>
 __device__ __forceinline__ void fill_flush_table(int comp, int b, int P, int F, float* dL_dverts, float* dL_dverts_color,
                                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                                                 float* dL_daa_face_verts, float** fl_base, SelT* fl_sel) {
+                                                 float* dL_daa_face_verts, float** fl_base, SelT* fl_sel, bool aa_to_verts = false) {
+    if (aa_to_verts && comp >= M_AA) {
+        const int within = comp - M_AA;
+        fl_base[comp] = dL_daa_face_verts + (int64_t)b * P * 2 + (within & 1);
+        fl_sel[comp] = (SelT)((within >> 1) | 0x80);
+        return;
+    }
     const int g = (comp >= M_DC) + (comp >= M_DZ) + (comp >= M_OP) + (comp >= M_IN) + (comp >= M_AA);   // 0..5: dverts, dcolor, dndc.z, dopacity, dintense, daa
     const int within = comp - (g == 0 ? M_DV : g == 1 ? M_DC : g == 2 ? M_DZ : g == 3 ? M_OP : g == 4 ? M_IN : M_AA);
     const int sel = g < 2 ? 1 + within / 3 : (g == 2 ? 1 + within : 0);
@@ -50,6 +58,16 @@ __device__ __forceinline__ void fill_flush_table(int comp, int b, int P, int F, 
     fl_base[comp] = (g == 0 ? dL_dverts : g == 1 ? dL_dverts_color : g == 2 ? dL_dverts_ndc : g == 3 ? dL_dfaces_opacity
                     : g == 4 ? dL_dfaces_intense : dL_daa_face_verts) + add;
     fl_sel[comp] = (SelT)(sel | (mult << 2));
+}
+
+// id selector (0: face_id, 1..3: vid[0..2]) and dwords per id of a flush-table entry, for a record with edge-flag word zmask
+__device__ __forceinline__ void flush_id_and_mult(int entry, uint32_t zmask, int& sel, int& mult) {
+    if (entry & 0x80) {                                   // an AA corner on its way to its vertex
+        const int c = entry & 3;
+        const bool flip = (zmask >> 8) & 1u;
+        sel = 1 + (c == 0 ? 0 : (flip ? 3 - c : c));
+        mult = 2;
+    } else { sel = entry & 3; mult = entry >> 2; }
 }
 
 }  // namespace dm2

@@ -85,6 +85,13 @@ typedef struct dm2_render_desc {
                                     normalised with + 1e-6 on the length.  Saves the two (B,H,W,3) tensors (49.8 MB per camera at
                                     1080p) and 24 B per pixel of reads in either pass. */
 
+#define DM2_FLAG_AA_GRAD_TO_VERTS 16 /* dm2_backward: the sixth output is not dL/d(aa_face_verts) (B,F,3,2) but that gradient already
+                                    scattered to the vertices it belongs to: a (B,P,2) array, zero-filled by the caller, that
+                                    receives dL/d(aa corner) at [b, vertex of that corner] (the CCW reorder of pyrenderer.py:8,521-529
+                                    undone: the forward's packed record remembers it).  What torch autograd does with
+                                    dL/d(aa_face_verts) in the reference's host prep, without the (B,F,3,2) round trip: for a caller
+                                    that owns the host prep as well (dmesh2_renderer_amd/prep.py). */
+
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 2 * (B*tiles) + 1 for Renderer (holds the packed face records,

@@ -167,6 +167,41 @@ def test_renderer_fused_prep_end_to_end():
         assert rel(b, a) <= 1e-3      # a 1-ulp difference of verts_image moves AA areas by ~1e-6; gradients amplify it
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_fused_aa_gradient_routing(legacy):
+    """With the fused prep the op returns its AA-corner gradients per VERTEX (DM2_FLAG_AA_GRAD_TO_VERTS: the gradient of
+    verts_image, the CCW reorder undone from the packed record) instead of dL/d(aa_face_verts): same leaf gradients as the
+    reference's route through the (B,F,3,2) tensor, on a scene with both orientations and shared vertices, on the dense
+    and on the per-pixel-walk kernels."""
+    import dmesh2_renderer_amd as dm2
+    from dmesh2_renderer_amd import _C
+    W, H, F = 112, 72, 900
+    sc = mixed_orientation(scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 47, num_cams=2, shared_verts=True)).to("cuda")
+    pm = torch.tensor([[8, 4], [0, 0]], dtype=torch.int64, device="cuda")
+    pw, ph = 96, 64
+    gen = torch.Generator().manual_seed(11)
+    gc, gd = torch.randn((2, ph, pw, 3), generator=gen).cuda(), torch.randn((2, ph, pw), generator=gen).cuda()
+    res = []
+    old_flags = _C.set_flags(_C.DM2_FLAG_LEGACY_KERNELS if legacy else 0)
+    old_mode = dm2._FUSED_AA_GRAD
+    try:
+        for routed in (False, True):
+            dm2._FUSED_AA_GRAD = routed
+            r = dm2.Renderer(sc.mv, sc.proj, W, H, "cuda", fused_prep=True)
+            leaves = [t.clone().requires_grad_(True) for t in (sc.verts, sc.verts_color, sc.faces_opacity, sc.faces_intense)]
+            color, depth = r([1, 0], pm, pw, ph, leaves[0], sc.faces, leaves[1], leaves[2], leaves[3], sc.background, aa_temperature=1.0)
+            torch.autograd.backward([color, depth], [gc, gd])
+            res.append((color.detach().cpu().numpy(), [t.grad.cpu().numpy() for t in leaves]))
+    finally:
+        dm2._FUSED_AA_GRAD = old_mode
+        _C.set_flags(old_flags)
+    (c0, g0), (c1, g1) = res
+    assert np.array_equal(c0, c1)
+    assert np.abs(g0[0]).max() > 0
+    for a, b in zip(g0, g1):
+        assert rel(b, a) <= 1e-5
+
+
 def test_layered_renderer_fused_projection():
     import dmesh2_renderer_amd as dm2
     sc = scenes.tet_lattice(64, 64, 4, scenes.SEED_BASE + 46).to("cuda")

@@ -182,23 +182,29 @@ class BandShardedOp:
         self.fwd = self._C.render_forward_cuda(*self.args)
         return self.fwd[1], self.fwd[2]
 
-    def backward(self, dL_dcolor_band, dL_ddepth_band, group=None, reduce=True):
-        """Band gradients -> full gradients (summed over ranks when ``reduce``)."""
+    def backward(self, dL_dcolor_band, dL_ddepth_band, group=None, reduce=True, aa_to_verts=False):
+        """Band gradients -> full gradients (summed over ranks when ``reduce``).  ``aa_to_verts``: the sixth gradient is
+        (B,P,2), the AA-corner gradients already scattered to the vertices (``_C.aa_grad_to_verts``)."""
         a = self.args
         if self.rows == 0:
             P, F, B = a[4].shape[0], a[5].shape[0], a[8].shape[0]
             dev = a[4].device
             # (the physical order of _C.render_backward_cuda: every rank must take the same path through the collectives)
-            sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * F * 6]
+            sizes = [P * 3, P * 3, F, B * F, B * P * 3, B * P * 2 if aa_to_verts else B * F * 6]
             packed = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
             parts = torch.split(packed, sizes)
             grads = (parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(F), parts[4].view(B, P, 3),
-                     parts[3].view(B, F), parts[5].view(B, F, 3, 2))
+                     parts[3].view(B, F), parts[5].view(B, P, 2) if aa_to_verts else parts[5].view(B, F, 3, 2))
             grads[0]._dm2_packed = packed
         else:
             f = self.fwd
-            grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
-                                                 f[3], f[4], f[5], f[6])
+            if aa_to_verts:
+                with self._C.aa_grad_to_verts(True):
+                    grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
+                                                         f[3], f[4], f[5], f[6])
+            else:
+                grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
+                                                     f[3], f[4], f[5], f[6])
         if reduce and self.world_size > 1:
             grads = allreduce_packed_grads(grads, group)
         return grads
@@ -225,7 +231,10 @@ class BandShardedOp:
         __init__.py:239-262 and pyrenderer.py:6-30; here ``_C.prepare_faces_backward``).
         """
         import torch.distributed as dist
-        g = self.backward(dL_dcolor_band, dL_ddepth_band, reduce=False)
+        # with the product backend the AA-corner gradients arrive per vertex: no (B,F,3,2) scatter pass over all faces on
+        # every rank (DM2_FLAG_AA_GRAD_TO_VERTS)
+        routed = prep_backward is None and hasattr(self._C, "aa_grad_to_verts")
+        g = self.backward(dL_dcolor_band, dL_ddepth_band, reduce=False, aa_to_verts=routed)
         dverts, dcolor, dopacity, dndc, dintense, daa = g
         verts, faces, mv, proj, width, height = prep_inputs
         pb = prep_backward or self._C.prepare_faces_backward
@@ -242,7 +251,10 @@ class BandShardedOp:
             # the op's own gradients of colour / opacity / intensity are final: their all-reduce starts now and runs while
             # the host-prep backward below adds its share to dverts
             early = dist.all_reduce(packed[n_v:n_v + n_rest], op=dist.ReduceOp.SUM, group=group, async_op=True)
-        dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
+        if routed:
+            dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_verts_image=daa)
+        else:
+            dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
         if not dense:
             touched = self.touched_faces()
             if touched is None:      # backend without the scratch accessor: any face or vertex row that is not exactly zero

@@ -332,6 +332,8 @@ def render_forward_cuda(*args):
     d, dev, (B, P, F, W, H, K) = _make_desc(args, keep)
     if getattr(_tls, "forward_only", False):
         d.flags |= DM2_FLAG_NO_BACKWARD
+    if getattr(_tls, "aa_to_verts", False):
+        d.flags |= DM2_FLAG_AA_GRAD_TO_VERTS          # the packed records note the CCW reorder for the backward
     with torch.cuda.device(dev):
         st = _stream(dev)
         f32, i32 = torch.float32, torch.int32

@@ -459,12 +459,15 @@ k_render_backward_mask(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         if (comp < M_N) {
             float* const basep = s_fl_base[comp];                                 // (per-component table, filled in the prologue)
             const int entry = s_fl_sel[comp];
+            const bool corner = (entry & 0x80) != 0;                              // DM2_FLAG_AA_GRAD_TO_VERTS: an AA corner on its way to its vertex
+            int sel0, mult;
+            flush_id_and_mult(entry, 0u, sel0, mult);
             for (int e = tid >> 5; e < n; e += TILE_PIX / 32) {
                 float* a = acc + e * BM_ACC;
                 const float flag = a[M_FLAG];                                     // (the 32 lanes of an entry sit in one wave)
                 const float val = a[comp];
-                int sel, mult;
-                flush_id_and_mult(entry, recs[e].aa.zmask, sel, mult);
+                int sel = sel0;
+                if (corner) { int m_; flush_id_and_mult(entry, recs[e].aa.zmask, sel, m_); }   // (the record knows the reorder)
                 const int id = (&recs[e].face_id)[sel];
                 if (flag != 0.f) {
                     a[comp] = 0.f;                                                // ready for the next chunk

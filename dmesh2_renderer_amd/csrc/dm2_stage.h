@@ -112,8 +112,10 @@ __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int f
     }
     // bit 8: the CCW reorder swapped corners 1 and 2 (pyrenderer.py:8,521-529): aa corner 1 is not this face's vertex 1
     // (DM2_FLAG_AA_GRAD_TO_VERTS routes the corner gradients back with it; bits 0..5 are the edge flags)
-    const float2 iv1 = *reinterpret_cast<const float2*>(d.verts_image + ((int64_t)b * d.P + v1) * 2);
-    if (!(av[1].x == iv1.x && av[1].y == iv1.y)) zm |= 1u << 8;
+    if (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) {                    // (only a forward that announces such a backward pays the gather)
+        const float2 iv1 = *reinterpret_cast<const float2*>(d.verts_image + ((int64_t)b * d.P + v1) * 2);
+        if (!(av[1].x == iv1.x && av[1].y == iv1.y)) zm |= 1u << 8;
+    }
     r.aa.zmask = zm;
     // aa_face_verts.min(2)/.max(2)  (forward.cu:480-481, backward.cu:589-590)
     r.aa.bb[0] = fminf(fminf(r.aa.v[0], r.aa.v[2]), r.aa.v[4]);

@@ -159,6 +159,9 @@ class BandShardedOp:
         from . import _C
         self._C = backend or _C
         self.world_size, self.rank = world_size, rank
+        # the product backend can hand the AA-corner gradients back per vertex (DM2_FLAG_AA_GRAD_TO_VERTS; announced in the
+        # forward, used by backward_leaves): no (B,F,3,2) scatter pass over all faces on every rank
+        self.routed = hasattr(self._C, "aa_grad_to_verts")
         a = list(full_args)
         H = int(a[3])
         self.y0, self.rows = band_rows(H, world_size, rank)
@@ -179,7 +182,11 @@ class BandShardedOp:
             dev = a[8].device
             self.fwd = None
             return torch.zeros((B, 0, W, 3), device=dev), torch.zeros((B, 0, W), device=dev)
-        self.fwd = self._C.render_forward_cuda(*self.args)
+        if self.routed:          # (the forward's packed records note the CCW reorder the routed backward needs)
+            with self._C.aa_grad_to_verts(True):
+                self.fwd = self._C.render_forward_cuda(*self.args)
+        else:
+            self.fwd = self._C.render_forward_cuda(*self.args)
         return self.fwd[1], self.fwd[2]
 
     def backward(self, dL_dcolor_band, dL_ddepth_band, group=None, reduce=True, aa_to_verts=False):
@@ -233,7 +240,7 @@ class BandShardedOp:
         import torch.distributed as dist
         # with the product backend the AA-corner gradients arrive per vertex: no (B,F,3,2) scatter pass over all faces on
         # every rank (DM2_FLAG_AA_GRAD_TO_VERTS)
-        routed = prep_backward is None and hasattr(self._C, "aa_grad_to_verts")
+        routed = prep_backward is None and self.routed
         g = self.backward(dL_dcolor_band, dL_ddepth_band, reduce=False, aa_to_verts=routed)
         dverts, dcolor, dopacity, dndc, dintense, daa = g
         verts, faces, mv, proj, width, height = prep_inputs

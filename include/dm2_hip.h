@@ -90,7 +90,8 @@ typedef struct dm2_render_desc {
                                     receives dL/d(aa corner) at [b, vertex of that corner] (the CCW reorder of pyrenderer.py:8,521-529
                                     undone: the forward's packed record remembers it).  What torch autograd does with
                                     dL/d(aa_face_verts) in the reference's host prep, without the (B,F,3,2) round trip: for a caller
-                                    that owns the host prep as well (dmesh2_renderer_amd/prep.py). */
+                                    that owns the host prep as well (dmesh2_renderer_amd/prep.py).  The flag must be set in the
+                                    forward call of the same frame too: that is when the record notes the reorder. */
 
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {

@@ -37,7 +37,8 @@ int fail(const std::string& m) { g_err = m; return 1; }
 
 struct PinnedWord {     // per-thread mapped host words for the plan's read-back
     uint32_t* p = nullptr;      // host view: [0] num_rendered [1] longest tile list [2] sequence word
-    uint32_t* dp = nullptr;     // device view of the same memory
+    uint32_t* dp = nullptr;     // device view of the same memory, for device `dev`
+    int dev = -1;
     uint32_t seq = 0;
     hipEvent_t ev = nullptr;
     ~PinnedWord() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
@@ -50,11 +51,16 @@ thread_local PinnedWord g_pin;
 // kernel has retired), the classical route takes over: an event behind a device-to-host copy of the device-side words.
 int plan_meta_prepare(uint32_t** host_meta_dev, uint32_t* seq) {
     if (!g_pin.p) {
-        DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocMapped));
+        DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocMapped | hipHostMallocPortable));
         g_pin.p[0] = g_pin.p[1] = g_pin.p[2] = 0u;
+    }
+    int cur = 0;
+    DM2_HIP(hipGetDevice(&cur));
+    if (cur != g_pin.dev) {                                               // (a thread that moves to another GPU: that GPU's view)
         void* dp = nullptr;
         DM2_HIP(hipHostGetDevicePointer(&dp, g_pin.p, 0));
-        g_pin.dp = (uint32_t*)dp;
+        g_pin.dp = (uint32_t*)dp; g_pin.dev = cur;
+        if (g_pin.ev) { (void)hipEventDestroy(g_pin.ev); g_pin.ev = nullptr; }     // (events belong to a device as well)
     }
     if (!g_pin.ev) DM2_HIP(hipEventCreateWithFlags(&g_pin.ev, hipEventDisableTiming));
     g_pin.seq = g_pin.seq + 1u ? g_pin.seq + 1u : 1u;                      // never 0: the words start out as 0

@@ -375,7 +375,7 @@ int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, con
                          const uint8_t* aa_face_edges_iszero, const float* aa_face_edges_recip, const float* aa_face_edges_normal,
                          const float* aa_face_edges_normal_c, const float* pixmin, float* area, float* grad, int32_t* code,
                          void* stream) {
-    if (variant < 0 || variant > 3) return fail("dm2_debug_aa_overlap: unknown variant");
+    if (variant < 0 || variant > 4) return fail("dm2_debug_aa_overlap: unknown variant");
     if (n < 0) return fail("dm2_debug_aa_overlap: negative count");
     if (n > 0 && (!aa_face_verts || !aa_face_edges || !aa_face_edges_iszero || !aa_face_edges_recip || !aa_face_edges_normal ||
                   !aa_face_edges_normal_c || !pixmin || !area || !grad || !code))

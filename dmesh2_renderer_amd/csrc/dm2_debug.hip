@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dm2_clip_area.h"
+#include "dm2_clip_fast.h"
 #include "dm2_clip_seg.h"
 #include "dm2_device_math.h"
 #include "dm2_state.h"
@@ -36,12 +37,20 @@ k_debug_aa_overlap(int variant, int64_t n, const float* __restrict__ tv, const f
         err = tri_pix_overlap_area<true>(f, pxmin, pxmax, pymin, pymax, 1.0f, a, g);
     } else if (variant == 1) {         // forward (dm2_forward_queue.hip): bbox reject, classification, straight-line area clipper
         err = tri_pix_overlap_area_only(f, pxmin, pxmax, pymin, pymax, 1.0f, a);
+    } else if (variant == 4) {         // backward (dm2_backward_fast.hip): the forward's decision and area, the Jacobian without a polygon;
+                                       // code -1: the pair is a tie and goes to the segment formulation instead (grad zeroed here)
+        err = tri_pix_overlap_area_only(f, pxmin, pxmax, pymin, pymax, 1.0f, a);
+        if (err == 0 && a != 0.0f) {
+            bool tie;
+            fast_area_grad(f, pxmin, pxmax, pymin, pymax, g, tie);
+            if (tie) { err = -1; for (int k = 0; k < 6; k++) g[k] = 0.f; }
+        }
     } else {                           // backward (dm2_backward_mask.hip): the forward's decision, then the segment formulation
         float af = 0.f;
         err = tri_pix_overlap_area_only(f, pxmin, pxmax, pymin, pymax, 1.0f, af);
         if (err == 0 && af != 0.0f) seg_area_grad(f, pxmin, pxmax, pymin, pymax, 1.0f, a, g, variant == 3);   // 3: with the exact fan-sum area
     }
-    if (err != 0) { a = 0.f; for (int k = 0; k < 6; k++) g[k] = 0.f; }
+    if (err > 0) { a = 0.f; for (int k = 0; k < 6; k++) g[k] = 0.f; }
     area[i] = a; code[i] = err;
     for (int k = 0; k < 6; k++) grad[6 * i + k] = g[k];
 }

@@ -7,7 +7,9 @@ Bars: the generic clipper of the per-pixel-walk kernels (variant 0) and the forw
 (variant 1) are bit-equal to the CPU oracle -- area, and for variant 0 the Jacobian in the reference's fan order; the
 backward's segment formulation (variant 2; the same polynomial regrouped, see dm2_clip_seg.h; variant 3: with the
 reference's fan sum over its corners, the area bit-equal as well) agrees to 2 ulp of the
-pixel area and 1e-6 absolute in the Jacobian.  All three report an error exactly where the reference raises."""
+pixel area and 1e-6 absolute in the Jacobian.  All three report an error exactly where the reference raises.
+Variant 4 is the default backward's Jacobian without a polygon (dm2_clip_fast.h): every pair it does NOT hand to the
+segment formulation as a tie (code -1) is held to the oracle's Jacobian; the ties are variant 2's."""
 import os
 
 import numpy as np
@@ -204,3 +206,83 @@ def test_device_clippers_exact_ties():
             assert np.array_equal(area.view(np.uint32), o_area.view(np.uint32)), variant
             if variant == 0:
                 assert np.array_equal(grad.view(np.uint32), o_grad.view(np.uint32))
+
+
+# ---- variant 4: the Jacobian without a polygon (dm2_clip_fast.h) + its tie flag ------------------------------------
+FAST_GRAD_TOL = 1e-5           # of max(1, largest Jacobian entry); 2e-7 typical, 8e-6 the largest seen
+
+
+def _check_fast(g, o_area, o_grad, o_code, max_tie_fraction=None, min_ok=10):
+    area, grad, code = _device_run(g, 4)
+    assert np.array_equal(code > 0, o_code != 0)                      # errors exactly where the reference raises
+    live = (o_code == 0) & (o_area != 0)
+    assert np.array_equal(area[live].view(np.uint32), o_area[live].view(np.uint32))     # (the forward's area)
+    tie = code == -1
+    assert not (tie & ~live).any()
+    ok = live & ~tie
+    assert ok.sum() >= min_ok, ok.sum()
+    err = _grad_err(grad, o_grad)
+    assert err[ok].max() <= FAST_GRAD_TOL, (err[ok].max(), np.where(ok & (err > FAST_GRAD_TOL))[0][:10])
+    if max_tie_fraction is not None:
+        assert tie[live].mean() <= max_tie_fraction, tie[live].mean()
+    # and the ties go to the segment formulation, held to its own bar above
+    return tie[live].mean(), err[ok].max()
+
+
+@pytest.mark.parametrize("name", ["aa_pairs.npz", "aa_error_pairs.npz"])
+def test_fast_jacobian_on_reference_vectors(name):
+    g = _load(name)
+    o_area, o_grad, o_code = _oracle_run(g)
+    _check_fast(g, o_area, o_grad, o_code, min_ok=100 if name == "aa_pairs.npz" else 1)     # (the second file is all near-ties)
+    area, grad, code = _device_run(g, 4)
+    ok = (o_code == 0) & (o_area != 0) & (code == 0)
+    assert np.allclose(grad[ok], g["grad_analytic"][ok], rtol=1e-5, atol=2e-6)    # the reference's own numbers
+
+
+@pytest.mark.parametrize("base,radius,n", [(10.0, 2.5, 20000), (1000.0, 2.5, 40000), (1900.0, 0.7, 20000), (500.0, 12.0, 20000),
+                                            (300.0, 60.0, 10000), (3800.0, 3.0, 40000)])
+def test_fast_jacobian_random_pairs(base, radius, n):
+    """Pairs in general position: the polygon-free Jacobian IS the oracle's (same corner coordinates, same polynomial);
+    a few per cent are flagged as ties (more at 4K coordinates and for sub-pixel triangles, whose every pair has a corner
+    near the pixel)."""
+    from oracle import cpu as orc
+    tris, pms = _random_pairs(int(base) * 7 + int(radius * 10) + 1, n, base, radius)
+    with np.errstate(divide="ignore"):
+        t = orc.aa_tables(tris, np.float32, reorder=True)
+    g = dict(t_verts=t["verts"], t_edges=t["edges"], t_edges_iszero=t["iszero"], t_edges_recip=t["recip"],
+             t_edges_normal=t["normal"], t_edges_normal_c=t["normal_c"], pixmin=pms)
+    o_area, o_grad, o_code = _oracle_run(g)
+    frac, worst = _check_fast(g, o_area, o_grad, o_code, max_tie_fraction=0.08)
+    print(f"fast Jacobian base {base} radius {radius}: ties {frac:.3%}, worst error {worst:.2e}")
+
+
+def _axis_pairs(seed, n):
+    """Faces with exactly axis-parallel edges (a regular grid mesh seen head-on): recip = inf, crossing parameters inf."""
+    rng = np.random.RandomState(seed)
+    tris = np.zeros((n, 3, 2), np.float32); pms = np.zeros((n, 2), np.float32)
+    for it in range(n):
+        base = rng.choice([8, 300, 1500])
+        o = (rng.uniform(0, 6, 2) + base).astype(np.float32)
+        s = np.float32(rng.uniform(0.8, 6.0)); u = np.float32(rng.uniform(0.8, 6.0))
+        kind = it % 3
+        if kind == 0:
+            tri = np.array([o, o + [s, 0], o + [0, u]], np.float32)                  # right angle, two axis-parallel edges
+        elif kind == 1:
+            tri = np.array([o + [s, u], o + [0, u], o + [s, 0]], np.float32)
+        else:
+            tri = np.array([o, o + [s, 0], o + rng.uniform(0.5, 5, 2)], np.float32)  # one axis-parallel edge
+        tris[it] = tri
+        pms[it] = np.floor(o + rng.uniform(-1, 6, 2))
+    return tris, pms
+
+
+def test_fast_jacobian_axis_parallel_and_ties():
+    from oracle import cpu as orc
+    for (tris, pms), cap in ((_axis_pairs(3, 12000), 0.08), (_tie_pairs(5, 12000), None), (_tie_pairs(11, 12000), None)):
+        with np.errstate(all="ignore"):
+            t = orc.aa_tables(tris, np.float32, reorder=True)
+            g = dict(t_verts=t["verts"], t_edges=t["edges"], t_edges_iszero=t["iszero"], t_edges_recip=t["recip"],
+                     t_edges_normal=t["normal"], t_edges_normal_c=t["normal_c"], pixmin=pms)
+            o_area, o_grad, o_code = _oracle_run(g)
+        frac, worst = _check_fast(g, o_area, o_grad, o_code, max_tie_fraction=cap)
+        print(f"fast Jacobian: ties {frac:.3%}, worst error {worst:.2e}")

@@ -31,11 +31,14 @@ DM2_FLAG_LEGACY_KERNELS = 2
 DM2_FLAG_NO_BACKWARD = 4
 DM2_FLAG_ANALYTIC_RAYS = 8
 DM2_FLAG_AA_GRAD_TO_VERTS = 16
-SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS = 0, 1, 2, 3, 4
+SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS, SCRATCH_PAIR_POOL, SCRATCH_TIE_QUEUE = range(7)
+# what a forward left for its backward (include/dm2_hip.h DM2_FWD_*)
+FWD_UNKNOWN, FWD_NONE, FWD_MASKS, FWD_POOL = 0, 1, 2, 3
+ABI_VERSION = 6
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
 _flags = 0
-_bin_hint: dict = {}      # (device, B, W, H, F) -> bytes of binning scratch that held the last forward of that shape
+_bin_hint: dict = {}      # (device, B, W, H, F) -> bytes of binning scratch (+ pair pool) that held the last forward of that shape; under _lock
 
 _vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 
@@ -76,11 +79,12 @@ EXPORTS = {
     "dm2_abi_version": (ctypes.c_int, []),
     "dm2_last_error": (ctypes.c_char_p, []),
     "dm2_scratch_bytes": (_sz, [ctypes.c_int, _i64, _i64]),
-    "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "dm2_forward_plan": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dm2_forward_run": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp,
+                                       ctypes.POINTER(_i32)]),
     "dm2_forward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp,
-                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz,
+                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
+    "dm2_backward": (ctypes.c_int, [ctypes.POINTER(RenderDesc), _i64, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_layers_plan": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _vp, _sz, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
@@ -124,7 +128,7 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dm2_abi_version() != 5:
+        if lib.dm2_abi_version() != ABI_VERSION:
             raise RuntimeError("dmesh2_renderer_amd: ABI version mismatch")
         if path is None:
             _lib = lib
@@ -306,6 +310,36 @@ class aa_grad_to_verts:
         _tls.aa_to_verts = self.old
 
 
+class forward_mode:
+    """``with _C.forward_mode(mode): _C.render_backward_cuda(...)`` -- tells the backward what the forward of this frame left
+    for it (FWD_NONE / FWD_MASKS / FWD_POOL, as ``_C.last_forward_mode()`` reported right after that forward), so that it
+    launches exactly one composite kernel.  Without it the binning buffer's own note is used when the very tensor object the
+    forward returned comes back; otherwise (FWD_UNKNOWN) every candidate kernel is launched and all but one return at once.
+    A side channel like ``forward_only``: the 31-argument signature stays the reference's."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = getattr(_tls, "fwd_mode", None)
+        _tls.fwd_mode = self.mode
+
+    def __exit__(self, *exc):
+        _tls.fwd_mode = self.old
+
+
+def last_forward_mode():
+    """FWD_* of the calling thread's most recent render_forward_cuda."""
+    return getattr(_tls, "last_fwd_mode", FWD_UNKNOWN)
+
+
+def _pool_budget(N, R):
+    """Pairs the shim is willing to give pool room to (4 B each in the binning buffer + 16 B each of backward scratch): a
+    frame whose plan counts more candidate pairs than this -- thousands of screen-filling faces -- keeps blend masks only
+    and its backward re-clips (DM2_FWD_MASKS)."""
+    return max(64 * N, 8 * R, 1 << 22)
+
+
 def _analytic(B, dev):
     a = getattr(_tls, "analytic", None)
     if a is None:
@@ -352,27 +386,36 @@ def render_forward_cuda(*args):
         tri_cnt = torch.empty((B, H, W), dtype=i32, device=dev)
         face_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_FACE, BF, 2 * Tn + 1))
         img_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_IMAGE, N, Tn))
-        nr, longest = _i64(0), _i64(0)
-        # the binning scratch is sized from the last call on this device (+ 25 %): when it fits -- every step of a training
-        # loop but the first -- plan and run are one C call and the GPU does not wait for Python in between
+        nr, longest, pairs, mode = _i64(0), _i64(0), _i64(0), _i32(0)
+        # the binning scratch (+ pair pool) is sized from the last call on this device (+ 25 %): when it fits -- every step of
+        # a training loop but the first -- plan and run are one C call and the GPU does not wait for Python in between
         key = (dev.index, B, W, H, F)
-        bin_buf = _bytes(dev, _bin_hint.get(key, 0))
+        with _lock:
+            hint = _bin_hint.get(key, 0)
+        bin_buf = _bytes(dev, hint)
         rc = lib.dm2_forward(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(), _ptr(img_buf), img_buf.numel(),
-                             _ptr(color), _ptr(depth), _ptr(tri_cnt), st, ctypes.byref(nr), ctypes.byref(longest))
+                             _ptr(color), _ptr(depth), _ptr(tri_cnt), st, ctypes.byref(nr), ctypes.byref(longest), ctypes.byref(pairs),
+                             ctypes.byref(mode))
         if rc not in (0, 2):
             raise _err(lib, "render_forward_cuda")
         R = int(nr.value)
-        need = lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn)
+        wants_pool = d.aa_temperature > 0.0 and not (d.flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS))
+        pool = lib.dm2_scratch_bytes(SCRATCH_PAIR_POOL, int(pairs.value), 0) if wants_pool and int(pairs.value) <= _pool_budget(N, R) else 0
+        need = lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn) + pool
         if rc == 2:
             bin_buf = _bytes(dev, need + need // 4)
-            if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(),
-                                   _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st):
+            if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), int(pairs.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf),
+                                   bin_buf.numel(), _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st,
+                                   ctypes.byref(mode)):
                 raise _err(lib, "render_forward_cuda (run)")
-        hint = _bin_hint.get(key, 0)
-        if need > hint or 2 * (need + need // 4) < hint:
-            if len(_bin_hint) > 64:
-                _bin_hint.clear()
-            _bin_hint[key] = need + need // 4
+        with _lock:
+            hint = _bin_hint.get(key, 0)
+            if need > hint or 2 * (need + need // 4) < hint:
+                if len(_bin_hint) > 64:
+                    _bin_hint.clear()
+                _bin_hint[key] = need + need // 4
+    _tls.last_fwd_mode = int(mode.value)
+    bin_buf._dm2_fwd_mode = int(mode.value)       # (survives only as long as this very tensor object is passed around)
     return R, color, depth, oarea, tri_id, tri_cnt, doarea, face_buf, bin_buf, img_buf
 
 
@@ -409,10 +452,21 @@ def render_backward_cuda(*args):
         if tuple(dL_dcolor.shape) != (B, H, W, 3) or tuple(dL_ddepth.shape) != (B, H, W):
             raise RuntimeError("dL_dout_color / dL_dout_depth must have dimensions (B, H, W, 3) / (B, H, W)")
         dc = _c(dL_dcolor, f32); dd = _c(dL_ddepth, f32)
+        mode = getattr(_tls, "fwd_mode", None)
+        if mode is None:
+            mode = getattr(bin_buf, "_dm2_fwd_mode", FWD_UNKNOWN)
         with torch.cuda.device(dev):
-            if lib.dm2_backward(ctypes.byref(d), num_rendered, _ptr(dc), _ptr(dd), _ptr(face_buf), face_buf.numel(),
-                                _ptr(bin_buf), bin_buf.numel(),
-                                _ptr(img_buf), img_buf.numel(), _ptr(g_verts), _ptr(g_color), _ptr(g_opac),
+            # scratch of this call: the queue of the pairs whose AA Jacobian the exact clipper has to supply -- room for one entry
+            # per pair of the binning buffer's pool part (written only for the 1-5 % that are ties)
+            tie_buf = None
+            if mode in (FWD_POOL, FWD_UNKNOWN) and d.aa_temperature > 0.0 and not (d.flags & DM2_FLAG_LEGACY_KERNELS):
+                pool_pairs = max(0, bin_buf.numel() - lib.dm2_scratch_bytes(SCRATCH_BINNING, num_rendered, _tiles(B, W, H))) // 4
+                if pool_pairs > 0:
+                    tie_buf = _bytes(dev, lib.dm2_scratch_bytes(SCRATCH_TIE_QUEUE, pool_pairs, 0))
+            if lib.dm2_backward(ctypes.byref(d), num_rendered, int(mode), _ptr(dc), _ptr(dd), _ptr(face_buf), face_buf.numel(),
+                                _ptr(bin_buf), bin_buf.numel(), _ptr(img_buf), img_buf.numel(),
+                                _ptr(tie_buf), tie_buf.numel() if tie_buf is not None else 0,
+                                _ptr(g_verts), _ptr(g_color), _ptr(g_opac),
                                 _ptr(g_ndc), _ptr(g_int), _ptr(g_aa), _stream(dev)):
                 raise _err(lib, "render_backward_cuda")
     g_verts._dm2_packed = packed

@@ -67,6 +67,7 @@ class RenderFunction(torch.autograd.Function):
             print("\nAn error occured in renderer forward.")
             print(ex)
             raise
+        ctx.fwd_mode = _C.last_forward_mode()       # what this forward left for its backward (masks, pair pool): picks the backward's kernel
         num_rendered, color, depth = out[0], out[1], out[2]
         opaque = out[3:]            # 4 AA-record tensors + face/binning/image byte buffers
         tensors_in = [x for x in inputs if torch.is_tensor(x)]
@@ -88,7 +89,8 @@ class RenderFunction(torch.autograd.Function):
         oarea, tri_id, tri_cnt, doarea, face_buf, binning_buf, image_buf = saved[ctx.n_tensor_in:]
         try:
             ana = ctx.analytic
-            with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))), _C.aa_grad_to_verts(ctx.aa_to_verts):
+            with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))), _C.aa_grad_to_verts(ctx.aa_to_verts), \
+                    _C.forward_mode(ctx.fwd_mode):
                 grads = _C.render_backward_cuda(
                     ctx.num_rendered, *inputs, grad_out_color, grad_out_depth,
                     face_buf, binning_buf, image_buf, oarea, tri_id, tri_cnt, doarea)

@@ -36,7 +36,7 @@ int fail(const std::string& m) { g_err = m; return 1; }
     } while (0)
 
 struct PinnedWord {     // per-thread mapped host words for the plan's read-back
-    uint32_t* p = nullptr;      // host view: [0] num_rendered [1] longest tile list [2] sequence word
+    uint32_t* p = nullptr;      // host view: [0] num_rendered [1] longest tile list [2,3] pair bound [4] sequence word
     uint32_t* dp = nullptr;     // device view of the same memory, for device `dev`
     int dev = -1;
     uint32_t seq = 0;
@@ -52,7 +52,7 @@ thread_local PinnedWord g_pin;
 int plan_meta_prepare(uint32_t** host_meta_dev, uint32_t* seq) {
     if (!g_pin.p) {
         DM2_HIP(hipHostMalloc((void**)&g_pin.p, 64, hipHostMallocMapped | hipHostMallocPortable));
-        g_pin.p[0] = g_pin.p[1] = g_pin.p[2] = 0u;
+        for (int k = 0; k < 8; k++) g_pin.p[k] = 0u;
     }
     int cur = 0;
     DM2_HIP(hipGetDevice(&cur));
@@ -67,27 +67,34 @@ int plan_meta_prepare(uint32_t** host_meta_dev, uint32_t* seq) {
     *host_meta_dev = g_pin.dp; *seq = g_pin.seq;
     return 0;
 }
-int plan_meta_wait(const uint32_t* plan_meta, hipStream_t st, int64_t* num_rendered, int64_t* max_tile_entries) {
+int plan_meta_wait(const uint32_t* plan_meta, hipStream_t st, int64_t* num_rendered, int64_t* max_tile_entries, int64_t* pair_bound) {
     DM2_HIP(hipEventRecord(g_pin.ev, st));                                 // (also tells whether the plan has retired)
     volatile uint32_t* hp = g_pin.p;
-    uint32_t r = 0, longest = 0;
+    uint32_t r = 0, longest = 0, plo = 0, phi = 0;
     bool seen = false;
+    auto take = [&]() { r = hp[0]; longest = hp[1]; plo = hp[2]; phi = hp[3]; seen = true; };
     for (long spin = 0; ; spin++) {
-        if (__atomic_load_n(&hp[2], __ATOMIC_ACQUIRE) == g_pin.seq) { r = hp[0]; longest = hp[1]; seen = true; break; }
-        if ((spin & 1023) == 1023 && hipEventQuery(g_pin.ev) != hipErrorNotReady) {
-            // the plan's kernels are done (or the stream is in error): the stores are visible now, or they never will be
-            if (__atomic_load_n(&hp[2], __ATOMIC_ACQUIRE) == g_pin.seq) { r = hp[0]; longest = hp[1]; seen = true; }
-            break;
+        if (__atomic_load_n(&hp[4], __ATOMIC_ACQUIRE) == g_pin.seq) { take(); break; }
+        if ((spin & 1023) == 1023) {
+            if (hipEventQuery(g_pin.ev) != hipErrorNotReady) {
+                // the plan's kernels are done (or the stream is in error): the stores are visible now, or they never will be
+                if (__atomic_load_n(&hp[4], __ATOMIC_ACQUIRE) == g_pin.seq) take();
+                break;
+            }
+            // earlier work still ahead of the plan on this stream (a caller that runs ahead): stop burning the core
+            if (spin > (1l << 17)) { (void)hipEventSynchronize(g_pin.ev); if (__atomic_load_n(&hp[4], __ATOMIC_ACQUIRE) == g_pin.seq) take(); break; }
         }
+        __builtin_ia32_pause();
     }
     if (!seen) {
-        uint32_t tmp[2] = {0u, 0u};
+        uint32_t tmp[4] = {0u, 0u, 0u, 0u};
         DM2_HIP(hipMemcpyAsync(tmp, plan_meta, sizeof(tmp), hipMemcpyDeviceToHost, st));
         DM2_HIP(hipStreamSynchronize(st));
-        r = tmp[0]; longest = tmp[1];
+        r = tmp[0]; longest = tmp[1]; plo = tmp[2]; phi = tmp[3];
     }
     *num_rendered = (int64_t)r;
     *max_tile_entries = (int64_t)longest;
+    if (pair_bound) *pair_bound = (int64_t)(((uint64_t)phi << 32) | plo);
     if (longest == 0xFFFFFFFFu) { *num_rendered = 0; *max_tile_entries = 0; return fail("more than 2^31 - 1 (tile, face) pairs: render smaller patches"); }
     return 0;
 }
@@ -184,18 +191,21 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
         case DM2_SCRATCH_BINNING: dm2::BinningState::carve(nullptr, count, dm2::sort_temp_bytes(count, aux), &total); break;
         case DM2_SCRATCH_LAYER_IMAGE: dm2::LayerImageState::carve(nullptr, count, aux, &total); break;
         case DM2_SCRATCH_LAYER_TETS: return dm2::tet_scratch_bytes(count);
+        case DM2_SCRATCH_PAIR_POOL: return dm2::BinningState::pool_bytes(count);
+        case DM2_SCRATCH_TIE_QUEUE: return count > 0 ? (size_t)count * sizeof(dm2::TieEntry) + dm2::ALIGN : 0;
         default: return 0;
     }
     return total;
 }
 
 static int forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
-                        int64_t* max_tile_entries, uint2* ranges_to_clear) {
+                        int64_t* max_tile_entries, int64_t* pair_bound, uint2* ranges_to_clear) {
     if (check_render_desc(d)) return 1;
     if (!num_rendered || !max_tile_entries) return fail("num_rendered / max_tile_entries is null");
     hipStream_t st = (hipStream_t)stream;
     const int64_t BF = (int64_t)d->B * d->F, Tn = tiles_of(d->B, d->W, d->H);
     *num_rendered = 0; *max_tile_entries = 0;
+    if (pair_bound) *pair_bound = 0;
     if (d->P == 0 || BF == 0 || Tn == 0) return 0;                       // render.cu:149
     if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
     dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
@@ -204,17 +214,18 @@ static int forward_plan(const dm2_render_desc* d, void* face_scratch, size_t fac
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d,
                                         host_meta, seq, ranges_to_clear, st));
     DM2_HIP(hipGetLastError());
-    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
+    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries, pair_bound);
 }
 
 int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
-                     int64_t* max_tile_entries) {
-    return forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, nullptr);
+                     int64_t* max_tile_entries, int64_t* pair_bound) {
+    return forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, nullptr);
 }
 
-static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
+static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, int64_t pair_bound, void* face_scratch, size_t face_bytes,
                        void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
-                       float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream, bool ranges_cleared) {
+                       float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream, bool ranges_cleared, int32_t* forward_mode) {
+    if (forward_mode) *forward_mode = DM2_FWD_NONE;
     if (check_render_desc(d)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int64_t BF = (int64_t)d->B * d->F, N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
@@ -227,43 +238,50 @@ static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t m
         if (dm2_scratch_bytes(DM2_SCRATCH_FACE, BF, 2 * Tn + 1) > face_bytes) return fail("face scratch too small");
         if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
         dm2::FaceState fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), true);
-        bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
+        bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn), nullptr, binning_bytes);
         is.face_recs = fs.recs;
         DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
                                      fs.depths, fs, bs, is.ranges, ranges_cleared, st));   // renderer.cu:192
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
-    dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs.hit_masks, bs.hit_valid, st);
+    // the pair pool is used when the caller appended room for every pair the plan counted (a smaller appendix is ignored)
+    const bool use_pool = have_faces && pair_bound > 0 && bs.pool_cap >= pair_bound;
+    const int mode = dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs, use_pool, st);
+    if (forward_mode) *forward_mode = mode;
     DM2_HIP(hipGetLastError());
     return 0;
 }
 
-int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, int64_t pair_bound, void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
-                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream) {
-    return forward_run(d, num_rendered, max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes, image_scratch,
-                       image_bytes, out_color, out_depth, out_tri_cnt, stream, false);
+                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream, int32_t* forward_mode) {
+    return forward_run(d, num_rendered, max_tile_entries, pair_bound, face_scratch, face_bytes, binning_scratch, binning_bytes, image_scratch,
+                       image_bytes, out_color, out_depth, out_tri_cnt, stream, false, forward_mode);
 }
 
 int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* binning_scratch, size_t binning_bytes,
                 void* image_scratch, size_t image_bytes, float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream,
-                int64_t* num_rendered, int64_t* max_tile_entries) {
+                int64_t* num_rendered, int64_t* max_tile_entries, int64_t* pair_bound, int32_t* forward_mode) {
     if (check_render_desc(d)) return 1;
+    if (!pair_bound) return fail("pair_bound is null");
+    if (forward_mode) *forward_mode = DM2_FWD_NONE;
     const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
     // the image scratch is at hand already: the plan's last kernel clears the tile ranges, one launch less in the run step
     uint2* ranges = nullptr;
     if (N > 0 && image_scratch && dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) <= image_bytes) ranges = dm2::ImageState::carve(image_scratch, N, Tn).ranges;
-    if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, ranges)) return 1;
+    if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, ranges)) return 1;
     const bool planned = d->P != 0 && (int64_t)d->B * d->F != 0 && Tn != 0;     // (otherwise no plan kernel ran)
-    if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) > binning_bytes) return 2;      // plan done; allocate, then dm2_forward_run
-    return forward_run(d, *num_rendered, *max_tile_entries, face_scratch, face_bytes, binning_scratch, binning_bytes,
-                       image_scratch, image_bytes, out_color, out_depth, out_tri_cnt, stream, planned && ranges != nullptr);
+    const bool wants_pool = d->aa_temperature > 0.0f && !(d->flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS));
+    if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) + (wants_pool ? dm2_scratch_bytes(DM2_SCRATCH_PAIR_POOL, *pair_bound, 0) : 0) > binning_bytes)
+        return 2;                                                                // plan done; allocate, then dm2_forward_run
+    return forward_run(d, *num_rendered, *max_tile_entries, *pair_bound, face_scratch, face_bytes, binning_scratch, binning_bytes,
+                       image_scratch, image_bytes, out_color, out_depth, out_tri_cnt, stream, planned && ranges != nullptr, forward_mode);
 }
 
-int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL_dout_color, const float* dL_dout_depth,
-                 const void* face_scratch, size_t face_bytes, const void* binning_scratch, size_t binning_bytes,
-                 const void* image_scratch, size_t image_bytes,
+int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, int32_t forward_mode, const float* dL_dout_color, const float* dL_dout_depth,
+                 const void* face_scratch, size_t face_bytes, void* binning_scratch, size_t binning_bytes,
+                 const void* image_scratch, size_t image_bytes, void* tie_scratch, size_t tie_bytes,
                  float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity, float* dL_dverts_ndc,
                  float* dL_dfaces_intense, float* dL_daa_face_verts, void* stream) {
     if (check_render_desc(d)) return 1;
@@ -275,11 +293,22 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, const float* dL
     if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
     dm2::ImageState is = dm2::ImageState::carve(const_cast<void*>(image_scratch), N, Tn);
-    dm2::BinningState bs = dm2::BinningState::carve(const_cast<void*>(binning_scratch), num_rendered,
-                                                    dm2::sort_temp_bytes(num_rendered, Tn));
+    if (forward_mode < DM2_FWD_UNKNOWN || forward_mode > DM2_FWD_POOL) return fail("forward_mode must be one of DM2_FWD_*");
+    dm2::BinningState bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn), nullptr, binning_bytes);
     is.face_recs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, Tn, dm2::scan_temp_bytes(BF), true).recs;
+    // the tie queue holds at most one entry per pair of the pool
+    dm2::TieEntry* tie_queue = nullptr; int64_t tie_cap = 0;
+    if (tie_scratch && tie_bytes >= sizeof(dm2::TieEntry) + dm2::ALIGN) {
+        dm2::Carver c(tie_scratch);
+        tie_queue = c.take<dm2::TieEntry>(0);
+        tie_cap = (int64_t)((tie_bytes - c.used(tie_scratch)) / sizeof(dm2::TieEntry));
+    }
+    if (forward_mode == DM2_FWD_POOL && d->aa_temperature > 0.0f && !(d->flags & DM2_FLAG_LEGACY_KERNELS)) {
+        if (bs.pool_cap <= 0) return fail("forward_mode is DM2_FWD_POOL but the binning scratch has no pool part");
+        if (tie_cap < bs.pool_cap) return fail("tie scratch too small for the pool part of the binning scratch");
+    }
     dm2::launch_render_backward(*d, is.ranges, bs.face_list, is, dL_dout_color, dL_dout_depth, dL_dverts, dL_dverts_color,
-                                dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs.hit_masks, bs.hit_valid, st);
+                                dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs, forward_mode, tie_queue, tie_cap, st);
     DM2_HIP(hipGetLastError());
     return 0;
 }
@@ -311,7 +340,7 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr,
                                         host_meta, seq, nullptr, st));
     DM2_HIP(hipGetLastError());
-    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries);
+    return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries, nullptr);
 }
 
 int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_tile_entries, void* face_scratch, size_t face_bytes,

@@ -42,8 +42,9 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
                   float* __restrict__ dL_dfaces_opacity, float* __restrict__ dL_dverts_ndc,
                   float* __restrict__ dL_dfaces_intense, float* __restrict__ dL_daa_face_verts,
                   const uint32_t* __restrict__ skip_if_masks) {
-    // launched behind k_render_backward_mask as its fallback: that kernel did the work when the forward left masks
-    if (skip_if_masks && skip_if_masks[0] == 2u) return;
+    // launched behind the mask-driven kernels when the caller did not know what the forward left (DM2_FWD_UNKNOWN): one of
+    // them did the work when the forward left masks
+    if (skip_if_masks && skip_if_masks[0] >= 2u) return;
     __shared__ FaceRec recs[BWD_CHUNK];
     __shared__ float acc[BWD_CHUNK * ACC_STRIDE];
     __shared__ uint32_t s_max_lc;
@@ -231,7 +232,11 @@ k_render_backward(dm2_render_desc d, const uint2* __restrict__ ranges, const uin
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                            float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st) {
+                            float* dL_daa_face_verts, const BinningState& bs, int fwd_mode, TieEntry* tie_queue, int64_t tie_cap,
+                            hipStream_t st) {
+    const uint64_t* const hit_masks = bs.hit_masks; const uint32_t* const hit_valid = bs.hit_valid;
+    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    StageTimer tm(ST_BWD, st);
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         // aa_temperature == 0: no bbox test in the reference (backward.cu:241-244), every face of a tile's list meets
         // all 256 pixels; the pair enumeration has nothing to prune there -> dm2_backward_point.hip (dense
@@ -244,21 +249,24 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
             return;
         }
 #endif
-        if (d.aa_temperature > 0.0f && hit_masks && hit_valid) {
-            // Two launches, one of which returns at once (decided on the device by hit_valid, no host read-back): when this
-            // frame's forward left its blend masks (dm2_forward_queue.hip), dm2_backward_mask.hip uses them; otherwise (the
-            // forward ran with DM2_FLAG_LEGACY_KERNELS) the per-pixel walk below does the work.
-            StageTimer tm(ST_BWD, st);
-            launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
-                                        dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
-            const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
-            hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                               dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid);
+        if (d.aa_temperature > 0.0f && hit_masks && hit_valid && fwd_mode != DM2_FWD_NONE) {
+            // What the forward left decides the kernel: masks + pool -> dm2_backward_fast.hip, masks -> dm2_backward_mask.hip,
+            // nothing -> the per-pixel walk.  A caller that says DM2_FWD_UNKNOWN gets all of them, each looking at hit_valid
+            // on the device (no host read-back) and all but one returning at once.
+            const bool unknown = fwd_mode == DM2_FWD_UNKNOWN;
+            const bool pool_ok = bs.pool && bs.pool_cap > 0 && tie_queue && tie_cap > 0;
+            if ((fwd_mode == DM2_FWD_POOL || unknown) && pool_ok)
+                launch_render_backward_fast(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color, dL_dfaces_opacity,
+                                            dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs, tie_queue, tie_cap, unknown, st);
+            if (fwd_mode == DM2_FWD_MASKS || unknown)
+                launch_render_backward_mask(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
+                                            dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_masks, hit_valid, st);
+            if (unknown)
+                hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+                                   dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, hit_valid);
             return;
         }
     }
-    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
-    StageTimer tm(ST_BWD, st);
     hipLaunchKernelGGL(k_render_backward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
                        dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
                        (const uint32_t*)nullptr);

@@ -168,6 +168,31 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             }
         }
     }
+    if (PACK) {
+        // Upper bound of the (pixel, face) pairs the forward composite will enumerate for this face: the patch pixels whose
+        // unit square passes the clipper's bounding-box test (aa.h:96-101; dm2_pairs.h face_pixel_rect, tile by tile).  The
+        // sum over the faces sizes the forward's pair pool (dm2_state.h), read back with num_rendered.
+        unsigned long long cand = 0;
+        if (touched != 0) {
+            const float bx0 = fminf(fminf(i0.x, i1.x), i2.x), bx1 = fmaxf(fmaxf(i0.x, i1.x), i2.x);
+            const float by0 = fminf(fminf(i0.y, i1.y), i2.y), by1 = fmaxf(fmaxf(i0.y, i1.y), i2.y);
+            if (bx0 == bx0 && bx1 == bx1 && by0 == by0 && by1 == by1) {
+                const float Wm = (float)(gx * TILE), Hm = (float)(gy * TILE);          // (>= the patch: an upper bound is all that is asked)
+                const float lo_x = fminf(fmaxf(ceilf(bx0) - 1.0f - (float)pmx, 0.0f), Wm), hi_x = fminf(fmaxf(floorf(bx1) - (float)pmx, -1.0f), Wm - 1.0f);
+                const float lo_y = fminf(fmaxf(ceilf(by0) - 1.0f - (float)pmy, 0.0f), Hm), hi_y = fminf(fmaxf(floorf(by1) - (float)pmy, -1.0f), Hm - 1.0f);
+                const float w = hi_x - lo_x + 1.0f, h = hi_y - lo_y + 1.0f;
+                if (w > 0.0f && h > 0.0f) cand = (unsigned long long)w * (unsigned long long)h;
+            }
+        }
+        // one atomic per wave (the active lanes are a prefix of the wave; a rectangle has at most 2^40 pixels: two limbs
+        // whose wave sums fit 32 bits, summed with the DPP scan)
+        const int sa = wave_inclusive_scan((int)(cand & 0xFFFFFFull)), sb = wave_inclusive_scan((int)(cand >> 24));
+        const int last = 63 - __clzll((long long)__ballot(true));
+        if ((int)(threadIdx.x & 63) == last) {
+            const unsigned long long tot = (unsigned long long)(uint32_t)sa + ((unsigned long long)(uint32_t)sb << 24);
+            if (tot) atomicAdd(fs.pair_part + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (PAIR_PARTS - 1)), tot);
+        }
+    }
     fs.tiles_touched[idx] = touched;
     fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
     fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
@@ -193,7 +218,8 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
 // kernel runs on, against 4.)
 __global__ void __launch_bounds__(1024)
 k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, uint32_t* __restrict__ start,
-            uint32_t* __restrict__ meta, uint32_t* host_meta, uint32_t host_seq, uint2* __restrict__ ranges_to_clear) {
+            const unsigned long long* __restrict__ pair_part, uint32_t* __restrict__ meta, uint32_t* host_meta, uint32_t host_seq,
+            uint2* __restrict__ ranges_to_clear) {
     constexpr int RUN = 8, ROUND = 1024 * RUN;
     __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
@@ -238,12 +264,14 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     __syncthreads();
     if (tid == 0) {
         const uint32_t longest = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max;      // (per-round totals stay below 2^32: 8192 tiles)
-        meta[0] = carry; meta[1] = longest;
+        unsigned long long pairs = 0;
+        for (int k = 0; k < PAIR_PARTS; k++) pairs += pair_part[k];
+        meta[0] = carry; meta[1] = longest; meta[2] = (uint32_t)pairs; meta[3] = (uint32_t)(pairs >> 32);
         if (host_meta) {
-            // the two numbers the host waits for, straight into its mapped memory, then the sequence word it polls: no copy
+            // the numbers the host waits for, straight into its mapped memory, then the sequence word it polls: no copy
             // command, no event -- the host learns them microseconds after this store instead of ~30 us later
-            host_meta[0] = carry; host_meta[1] = longest;
-            __hip_atomic_store(&host_meta[2], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            host_meta[0] = carry; host_meta[1] = longest; host_meta[2] = (uint32_t)pairs; host_meta[3] = (uint32_t)(pairs >> 32);
+            __hip_atomic_store(&host_meta[4], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -317,7 +345,7 @@ k_tile_sort(int64_t Tn, uint32_t R, const uint32_t* __restrict__ tile_start, uin
     const int tid = threadIdx.x;
     const uint32_t s0 = tile_start[t], e0 = (t + 1 < Tn) ? tile_start[t + 1] : R;
     const int n = (int)(e0 - s0);
-    if (t == 0 && tid == 0) *hit_valid = 0u;      // new lists: the blend masks of an earlier forward are stale
+    if (t == 0 && tid < 4) hit_valid[tid] = 0u;    // new lists: the blend masks of an earlier forward are stale; pool and tie queue empty
     if (tid == 0) ranges[t] = n ? make_uint2(s0, e0) : make_uint2(0u, 0u);
     if (n == 0) return;
     uint64_t* const seg = keys + s0;
@@ -407,7 +435,7 @@ __global__ void __launch_bounds__(256)
 k_tile_ranges(int64_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges, uint32_t* __restrict__ hit_valid) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
-    if (idx == 0) *hit_valid = 0u;          // new lists: the hit masks of an earlier point-sampled forward are stale
+    if (idx == 0) { hit_valid[0] = 0u; hit_valid[1] = 0u; hit_valid[2] = 0u; hit_valid[3] = 0u; }   // new lists: earlier masks are stale; pool and tie queue empty
     const uint32_t cur = (uint32_t)(keys[idx] >> 32);
     if (idx == 0) ranges[cur].x = 0;
     else {
@@ -462,14 +490,14 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
     if (Tn == 0) return hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
-    launch_zero_words(fs.tile_cnt, 2 * Tn, st);                            // (k_tile_scan writes plan_meta)
+    launch_zero_words(fs.tile_cnt, 2 * Tn + 2 * PAIR_PARTS, st);           // (the tile counts and the pair-bound partial sums; k_tile_scan writes plan_meta)
     if (pack && fs.recs)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.plan_meta, host_meta, host_seq,
-                       ranges_to_clear);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.pair_part, fs.plan_meta,
+                       host_meta, host_seq, ranges_to_clear);
     return hipSuccess;
 }
 

@@ -103,17 +103,19 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
     }
 }
 
-void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                           float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks, uint32_t* hit_valid,
-                           hipStream_t st) {
+int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                          float* out_color, float* out_depth, int32_t* out_tri_cnt, const BinningState& bs, bool use_pool,
+                          hipStream_t st) {
+    uint64_t* const hit_masks = bs.hit_masks; uint32_t* const hit_valid = bs.hit_valid;
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         if (d.aa_temperature > 0.0f) {
             // no backward will follow: no blend masks (hit_valid stays 0 from the binning, so a backward that comes
             // anyway takes the mask-free walk)
-            const bool masks = !(d.flags & DM2_FLAG_NO_BACKWARD);
+            const bool masks = !(d.flags & DM2_FLAG_NO_BACKWARD) && hit_masks && hit_valid;
+            const bool pool = masks && use_pool && bs.pool && bs.pool_cap > 0;
             launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, masks ? hit_masks : nullptr,
-                                        masks ? hit_valid : nullptr, st);
-            return;
+                                        masks ? hit_valid : nullptr, pool ? bs.pool : nullptr, pool ? bs.pool_cap : 0, bs.hit_base, st);
+            return pool ? DM2_FWD_POOL : (masks ? DM2_FWD_MASKS : DM2_FWD_NONE);
         }
         // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list meets
         // all 256 pixels: the per-pixel walk is the dense formulation there.  dm2_forward_point.hip is that walk with
@@ -122,7 +124,7 @@ void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const 
 #ifndef DM2_POINT_PER_PIXEL
         if (hit_masks && hit_valid) {
             launch_render_forward_point(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, hit_masks, hit_valid, st);
-            return;
+            return DM2_FWD_NONE;                          // (the point-sampled backward checks its own masks on the device)
         }
 #endif
     }
@@ -130,6 +132,7 @@ void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const 
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
     StageTimer tm(ST_FWD, st);
     hipLaunchKernelGGL(k_render_forward, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt);
+    return DM2_FWD_NONE;
 }
 
 }  // namespace dm2

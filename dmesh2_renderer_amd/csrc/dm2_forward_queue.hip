@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(TILE_PIX, DM2_FQ_BLOCKS)
 k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
                        int32_t* __restrict__ out_tri_cnt, uint64_t* __restrict__ hit_masks,
-                       uint32_t* __restrict__ hit_valid STAMP_PARAM) {
+                       uint32_t* __restrict__ hit_valid, float* __restrict__ pool, uint32_t pool_cap,
+                       uint32_t* __restrict__ hit_base STAMP_PARAM) {
     __shared__ FaceRec recs[FQ_CHUNK];                   // this chunk's faces; refilled (LDS-direct) behind phase B2, its last reader
     __shared__ uint32_t s_ids[64];                       // face ids of the NEXT chunk's list entries
     __shared__ FqPair s_pair[FQ_SURVCAP];
@@ -75,7 +76,9 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ uint16_t s_slot[FQ_PAIRCAP];              // per pair: survivors before it within its wave's range
     __shared__ uint32_t s_queue[4 * FQ_QCAP];            // survivors: q | face << 8 | corner mask << 14
     __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
-    __shared__ unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
+    __shared__ uint16_t s_ebase[4][FQ_CHUNK];            // [wave][face]: blended pairs of the chunk in front of the face (every wave scans for itself)
+    __shared__ uint32_t s_cbase;                         // pair pool: first slot of this chunk
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     uint32_t tile;
@@ -87,7 +90,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     STAMP_DECL
     fill_inv_table(s_inv);
     s_mask[tid] = 0;
-    if (hit_valid && blockIdx.x == 0 && tid == 0) hit_valid[0] = 2u;   // AA blend masks are current
+    if (hit_valid && blockIdx.x == 0 && tid == 0) hit_valid[0] = pool ? 3u : 2u;   // AA blend masks (+ the pair pool) are current
     const int lx = tid & 15, ly = tid >> 4;
     const int X0 = tile_x * TILE, Y0 = tile_y * TILE;
     const uint32_t px = X0 + lx, py = Y0 + ly;
@@ -226,11 +229,16 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
 
         if (base + n < total) request_ids(base + n);               // the next chunk's ids land during B2
+        // pair pool: the chunk takes one slot per survivor (>= the pairs that blend) -- one atomic per chunk, issued here and
+        // looked at behind B2
+        uint32_t cbase = 0;
+        if (pool && tid == 0) cbase = atomicAdd(hit_valid + 1, (uint32_t)S);
         // ---- phase B2: one survivor per lane ------------------------------------------------
         for (int s = tid; s < S; s += TILE_PIX) {
             const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
             const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
-            const uint32_t entry = s_queue[w * FQ_QCAP + (s - wb)];
+            uint32_t* const qslot = &s_queue[w * FQ_QCAP + (s - wb)];
+            const uint32_t entry = *qslot;
             const int q = (int)(entry & 255u), j = (int)((entry >> 8) & 63u);
             const uint32_t cmask = entry >> 14;
             const FaceRec& fc = recs[j];
@@ -262,7 +270,8 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                         out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
                         out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
                         out.alpha = fc.opacity * ratio;
-                        out.flags |= QF_BLEND;
+                        out.flags |= QF_BLEND | ((uint32_t)q << 8) | ((uint32_t)j << 16);
+                        *qslot = __float_as_uint(ratio);              // (the queue entry is spent: it keeps the coverage for the pool)
                     }
                 }
             }
@@ -270,15 +279,45 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 s_pair[s] = out;
                 atomicOr(&s_mask[q], 1ull << j);
                 if (hit_masks && (out.flags & QF_BLEND)) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
-            }
+            } else if (pool) s_pair[s].flags = 0;                     // (the pool pass below looks at every survivor's record)
         }
         STAMP(5)
+        if (pool && tid == 0) s_cbase = cbase;
         lds_prefetch_wait();
         __syncthreads();
         if (base + n < total) request_recs(base + n);              // B2 was the records' last reader: refill behind it
         // what the backward needs to find its work without re-classifying (dm2_backward_mask.hip): per list entry and
         // wave of the tile's block, the pixels the entry blends into
         if (hit_masks && tid < n * 4) hit_masks[((int64_t)range.x + base + (tid >> 2)) * 4 + (tid & 3)] = s_bmask[tid];
+        // ... and (dm2_backward_fast.hip) the coverage of every such pair, so that the backward neither clips for an area nor
+        // depends on reproducing it: pool slots in mask order -- entry by entry, wave by wave, pixel by pixel -- behind the
+        // chunk's first slot; per entry the slot of its first pair.  Every wave scans the entries' pair counts for itself.
+        if (pool) {
+            int cj = 0;
+            if (lane < n) {
+                const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane], m23 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane + 1];
+                cj = __popcll(m01.x) + __popcll(m01.y) + __popcll(m23.x) + __popcll(m23.y);
+            }
+            const int ex = wave_inclusive_scan(cj) - cj;
+            const uint32_t cb = s_cbase;
+            uint16_t* const erow = s_ebase[wid];
+            if (lane < FQ_CHUNK) erow[lane] = (uint16_t)ex;
+            if (wid == 0 && lane < n) hit_base[(int64_t)range.x + base + lane] = cb + (uint32_t)ex;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // (the lanes of the wave talk through erow with no barrier in between)
+            for (int s = tid; s < S; s += TILE_PIX) {
+                const uint32_t fl = s_pair[s].flags;
+                if (!(fl & QF_BLEND)) continue;
+                const int q = (int)((fl >> 8) & 255u), j = (int)((fl >> 16) & 63u), pw = q >> 6;
+                const unsigned long long* const mj = &s_bmask[j * 4];
+                int before = (int)erow[j];
+                before += (pw > 0 ? __popcll(mj[0]) : 0) + (pw > 1 ? __popcll(mj[1]) : 0) + (pw > 2 ? __popcll(mj[2]) : 0);
+                before += __popcll(mj[pw] & ((1ull << (q & 63)) - 1ull));
+                const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
+                const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
+                const uint32_t slot = cb + (uint32_t)before;
+                if (slot < pool_cap) pool[slot] = __uint_as_float(s_queue[w * FQ_QCAP + (s - wb)]);
+            }
+        }
 
         // ---- phase C: ordered blend of this pixel's records ---------------------------------
         {
@@ -320,11 +359,11 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
-                                 uint32_t* hit_valid, hipStream_t st) {
+                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, hipStream_t st) {
     const uint32_t Tn = (uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B);
     StageTimer tm(ST_FWD, st);
     hipLaunchKernelGGL(k_render_forward_queue, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt,
-                       hit_masks, hit_valid STAMP_ARG(0));
+                       hit_masks, hit_valid, pool, (uint32_t)pool_cap, hit_base STAMP_ARG(0));
 }
 
 }  // namespace dm2

@@ -34,6 +34,8 @@ struct Carver {
 // of indices), and again by the backward: the gradients belong to the inputs the forward saw.
 constexpr int FACE_REC_U4 = 16;            // uint4 per record (256 B)
 
+constexpr int PAIR_PARTS = 64;             // the plan's pair-bound sum is kept in this many partial sums (one atomic per wave, spread)
+
 // per (batch,face): produced by the preprocess kernel
 struct FaceState {
     float* depths;            // mean NDC z mapped to [0,1]  (sort key of Renderer)
@@ -49,7 +51,8 @@ struct FaceState {
     uint32_t* tile_cnt;       // (Tn)  list entries per tile from faces that touch at most four tiles (they keep their place, below)
     uint32_t* tile_cnt_big;   // (Tn)  list entries per tile from faces that touch more
     uint32_t* tile_start;     // (Tn)  exclusive scan of tile_cnt + tile_cnt_big
-    uint32_t* plan_meta;      // [0] num_rendered  [1] entries of the longest tile list
+    uint32_t* plan_meta;      // [0] num_rendered  [1] entries of the longest tile list  [2,3] pair bound (lo, hi)
+    unsigned long long* pair_part;   // (PAIR_PARTS) partial sums of the faces' pixel rectangles (their sum bounds the forward's (pixel,face) pairs)
     uint4* tile_rank;         // (BF)  faces with 1..4 tiles: the entry's place among the tile's small-face entries, rect order
     static FaceState carve(void* base, int64_t BF, int64_t Tn, size_t scan_temp_bytes, bool with_recs, size_t* total = nullptr) {
         Carver c(base); FaceState s;
@@ -58,7 +61,8 @@ struct FaceState {
         s.rect_lo = c.take<uint32_t>(BF); s.rect_hi = c.take<uint32_t>(BF);
         s.scan_temp = c.take<char>(scan_temp_bytes); s.scan_temp_bytes = scan_temp_bytes;
         s.recs = with_recs ? c.take<uint4>(BF * FACE_REC_U4) : nullptr;
-        s.tile_cnt = c.take<uint32_t>(2 * Tn); s.tile_cnt_big = s.tile_cnt + Tn;      // (one memset clears both)
+        s.tile_cnt = c.take<uint32_t>(2 * Tn + 2 * PAIR_PARTS); s.tile_cnt_big = s.tile_cnt + Tn;      // (one fill clears all three)
+        s.pair_part = reinterpret_cast<unsigned long long*>(s.tile_cnt + 2 * Tn);    // (8-byte aligned: the carve is 256-B aligned, 2 Tn words in front)
         s.tile_start = c.take<uint32_t>(Tn); s.plan_meta = c.take<uint32_t>(4);
         s.tile_rank = c.take<uint4>(Tn > 0 ? BF : 0);
         if (total) *total = c.used(base) + ALIGN;
@@ -100,20 +104,43 @@ struct BinningState {
     uint64_t* keys_unsorted;
     uint32_t* face_list_unsorted;
     void* sort_temp; size_t sort_temp_bytes;
-    // aa_temperature == 0 only: per list entry and wave of the tile's block, the 64 pixels the entry blended into in
-    // the forward (dm2_forward_point.hip writes, dm2_backward_point.hip reads); hit_valid[0] == 1 when they are current
+    // per list entry and wave of the tile's block, the 64 pixels the entry blended into in the forward (dm2_forward_point.hip /
+    // dm2_forward_queue.hip write, the mask-driven backward kernels read).  hit_valid[0]: what the forward left --
+    // 0 nothing (stale), 1 point-sampled masks, 2 AA blend masks, 3 AA blend masks + the pair pool
     uint64_t* hit_masks;          // (4 R)
-    uint32_t* hit_valid;          // (1)
-    static BinningState carve(void* base, int64_t R, size_t sort_temp_bytes, size_t* total = nullptr) {
+    uint32_t* hit_base;           // (R)  pair pool: slot of the entry's first blended pair (its pairs follow in (wave, pixel) order)
+    uint32_t* hit_valid;          // (4)  [0] mode  [1] pool slots handed out  [2] entries in the backward's tie queue
+    // pair pool (the tail of the buffer, whatever the caller appended to the fixed part): the coverage ratio
+    // (forward.cu:375-378) of every blended (pixel, face) pair, so that the backward neither clips for an area nor depends
+    // on reproducing it (dm2_backward_fast.hip)
+    float* pool; int64_t pool_cap;
+    static BinningState carve(void* base, int64_t R, size_t sort_temp_bytes, size_t* total = nullptr, size_t buffer_bytes = 0) {
         Carver c(base); BinningState s;
         s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
         s.keys_unsorted = c.take<uint64_t>(R); s.face_list_unsorted = c.take<uint32_t>(R);
         s.sort_temp = c.take<char>(sort_temp_bytes); s.sort_temp_bytes = sort_temp_bytes;
-        s.hit_masks = c.take<uint64_t>(4 * R); s.hit_valid = c.take<uint32_t>(1);
-        if (total) *total = c.used(base) + ALIGN;
+        s.hit_masks = c.take<uint64_t>(4 * R); s.hit_base = c.take<uint32_t>(R); s.hit_valid = c.take<uint32_t>(4);
+        const size_t fixed = c.used(base) + ALIGN;
+        if (total) *total = fixed;
+        s.pool = c.take<float>(0);
+        const size_t off = c.used(base);
+        s.pool_cap = buffer_bytes > off ? (int64_t)((buffer_bytes - off) / sizeof(float)) : 0;
+        if (s.pool_cap > 0xFFFFFFF0ll) s.pool_cap = 0xFFFFFFF0ll;      // slots are 32-bit
         return s;
     }
+    static size_t pool_bytes(int64_t pairs) { return pairs > 0 ? (((size_t)pairs * sizeof(float) + ALIGN - 1) & ~(ALIGN - 1)) + ALIGN : 0; }
 };
+
+// one entry of the backward's tie queue: a blended pair whose AA Jacobian the exact clipper has to supply
+// (patch pixel coordinates have up to 20 bits: the low 16 of each in `pxy`, the rest beside the view)
+struct __attribute__((aligned(16))) TieEntry { uint32_t face, view_hi, pxy; float dL_doarea; };
+__host__ __device__ inline TieEntry tie_pack(uint32_t face, uint32_t view, uint32_t x, uint32_t y, float g) {
+    TieEntry e; e.face = face; e.view_hi = view | ((x >> 16) << 16) | ((y >> 16) << 24); e.pxy = (x & 0xFFFFu) | (y << 16); e.dL_doarea = g;
+    return e;
+}
+__host__ __device__ inline void tie_unpack(const TieEntry& e, uint32_t& view, uint32_t& x, uint32_t& y) {
+    view = e.view_hi & 0xFFFFu; x = (e.pxy & 0xFFFFu) | (((e.view_hi >> 16) & 0xFFu) << 16); y = (e.pxy >> 16) | ((e.view_hi >> 24) << 16);
+}
 
 // ---- launchers implemented in the .hip files ------------------------------------
 size_t scan_temp_bytes(int64_t BF);
@@ -139,15 +166,17 @@ hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_ti
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
                                  uint32_t* hit_valid, hipStream_t st);
-void launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
-                           float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks, uint32_t* hit_valid,
-                           hipStream_t st);
+// use_pool: also fill the pair pool of `bs` (the caller has checked its capacity against the plan's pair bound).
+// Returns what it left for the backward (DM2_FWD_*).
+int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                          float* out_color, float* out_depth, int32_t* out_tri_cnt, const BinningState& bs, bool use_pool,
+                          hipStream_t st);
 void launch_prepare_faces(const dm2_prep_desc& d, hipStream_t st);
 void launch_prepare_faces_backward(const dm2_prep_desc& d, const float* g_ndc, const float* g_image, const float* g_aa,
                                    float* image_grad_scratch, float* g_verts, hipStream_t st);
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
-                                 uint32_t* hit_valid, hipStream_t st);
+                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, hipStream_t st);
 void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
@@ -156,10 +185,17 @@ void launch_render_backward_mask(const dm2_render_desc& d, const uint2* ranges, 
                                  const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                  float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
                                  float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
+void launch_render_backward_fast(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
+                                 const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
+                                 float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
+                                 float* dL_daa_face_verts, const BinningState& bs, TieEntry* tie_queue, int64_t tie_cap,
+                                 bool check_mode, hipStream_t st);
+// fwd_mode: DM2_FWD_* of the forward (DM2_FWD_UNKNOWN: every candidate kernel is launched and looks at hit_valid itself)
 void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                             const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                             float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,
-                            float* dL_daa_face_verts, const uint64_t* hit_masks, const uint32_t* hit_valid, hipStream_t st);
+                            float* dL_daa_face_verts, const BinningState& bs, int fwd_mode, TieEntry* tie_queue, int64_t tie_cap,
+                            hipStream_t st);
 void launch_debug_aa_overlap(int variant, int64_t n, const float* tv, const float* te, const uint8_t* tz, const float* tr,
                              const float* tn, const float* tc, const float* pixmin, float* area, float* grad, int32_t* code,
                              hipStream_t st);

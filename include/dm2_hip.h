@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DM2_ABI_VERSION 5
+#define DM2_ABI_VERSION 6
 #define DM2_TILE 16 /* config.h:4-5 BLOCK_X = BLOCK_Y = 16 */
 
 /* Inputs of Renderer's op, same meaning and order as render.h:13-45. */
@@ -101,8 +101,19 @@ enum {
     DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
     DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
     DM2_SCRATCH_LAYER_IMAGE = 3, /* count = B*H*W, aux = B*tiles    */
-    DM2_SCRATCH_LAYER_TETS = 4   /* count = T (tets): packed per-tet records of the layer walk, 256 B each */
+    DM2_SCRATCH_LAYER_TETS = 4,  /* count = T (tets): packed per-tet records of the layer walk, 256 B each */
+    DM2_SCRATCH_PAIR_POOL = 5,   /* count = pair_bound of the plan: bytes to APPEND to the binning scratch (behind its
+                                    DM2_SCRATCH_BINNING bytes for the same num_rendered) for the forward's pair pool: 4 B per
+                                    (pixel, face) pair, the coverage the backward would otherwise clip for again */
+    DM2_SCRATCH_TIE_QUEUE = 6    /* count = pairs the binning scratch's pool part holds (appended bytes / 4): scratch of ONE
+                                    dm2_backward call, 16 B per pair, written only for the pairs the exact clipper has to redo */
 };
+
+/* What a forward left for its backward: returned by dm2_forward / dm2_forward_run, to be handed to dm2_backward. */
+#define DM2_FWD_UNKNOWN 0  /* dm2_backward decides on the device: every candidate kernel is launched, all but one return at once */
+#define DM2_FWD_NONE 1     /* nothing (DM2_FLAG_NO_BACKWARD, DM2_FLAG_LEGACY_KERNELS): the per-pixel walk recomputes everything */
+#define DM2_FWD_MASKS 2    /* per list entry the pixels it blended into: the backward re-clips those pairs exactly */
+#define DM2_FWD_POOL 3     /* masks + pair pool: the default -- no clip for an area, Jacobians without a polygon */
 
 int dm2_abi_version(void);
 const char* dm2_last_error(void);
@@ -113,10 +124,12 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux);
 /* Bin faces into 16x16 tiles (preprocessFaceCUDA forward.cu:16-108) and count the
  * entries of every tile list; returns the number of (tile,face) pairs (`num_rendered`,
  * the reference's InclusiveSum of tiles_touched, renderer.cu:165-179) and the length of
- * the longest list (`max_tile_entries`, to be handed to dm2_forward_run).
- * Waits for the 8-byte read-back of those two numbers. */
+ * the longest list (`max_tile_entries`, to be handed to dm2_forward_run), and `pair_bound`: an upper bound of
+ * the (pixel, face) pairs the composite will look at (the faces' pixel rectangles inside the patch, summed) -- the
+ * size of the pair pool a caller may append to the binning scratch (DM2_SCRATCH_PAIR_POOL).
+ * Waits for the 16-byte read-back of those numbers. */
 int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
-                     void* stream, int64_t* num_rendered, int64_t* max_tile_entries);
+                     void* stream, int64_t* num_rendered, int64_t* max_tile_entries, int64_t* pair_bound);
 
 /* Per-tile lists ordered by (depth key, emission order) + tile ranges + per-pixel composite
  * (renderer.cu:185-266, FORWARD::renderCUDA forward.cu:139-432).  The lists are the ones the
@@ -129,34 +142,45 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
  * scratch must be kept (unmodified) for dm2_backward -- they are the three byte
  * buffers the reference returns and takes back (render.cu:194, render.h:79-81).
  * The face scratch holds a packed copy of the per-face inputs as the forward saw
- * them; the backward differentiates with respect to those. */
-int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries,
+ * them; the backward differentiates with respect to those.
+ * Pair pool: when binning_bytes >= DM2_SCRATCH_BINNING bytes + DM2_SCRATCH_PAIR_POOL bytes for pair_bound, the
+ * composite also leaves the coverage ratio (forward.cu:375-378) of every blended pair in the appended part and
+ * *forward_mode is DM2_FWD_POOL; otherwise DM2_FWD_MASKS (a caller that finds pair_bound too large for its memory
+ * simply appends nothing), or DM2_FWD_NONE under DM2_FLAG_NO_BACKWARD / DM2_FLAG_LEGACY_KERNELS / aa_temperature 0
+ * (the point-sampled kernels keep their own masks).  forward_mode may be NULL. */
+int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, int64_t pair_bound,
                     void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes,
                     void* image_scratch, size_t image_bytes,
-                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream);
+                    float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream, int32_t* forward_mode);
 
 /* dm2_forward_plan + dm2_forward_run in ONE call for a caller that already holds a binning scratch of plausible size (a
  * training loop: last frame's size plus headroom): the run step is enqueued straight from the plan's read-back, without
  * the round trip through the caller that otherwise leaves the GPU idle (~15 us of a 25-us gap through Python).
- * Returns 0 (rendered; *num_rendered / *max_tile_entries set), 2 when binning_bytes is smaller than
- * dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, B*tiles) -- the plan is done and nothing else: allocate and
- * call dm2_forward_run -- or 1 on error.  A larger-than-needed binning scratch is fine, also for dm2_backward. */
+ * Returns 0 (rendered; *num_rendered / *max_tile_entries / *pair_bound / *forward_mode set), 2 when binning_bytes is
+ * smaller than dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, B*tiles) + dm2_scratch_bytes(DM2_SCRATCH_PAIR_POOL,
+ * *pair_bound, 0) -- the plan is done and nothing else: allocate and call dm2_forward_run -- or 1 on error.  A
+ * larger-than-needed binning scratch is fine, also for dm2_backward (which must be given the same size). */
 int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
                 void* binning_scratch, size_t binning_bytes, void* image_scratch, size_t image_bytes,
                 float* out_color, float* out_depth, int32_t* out_tri_cnt, void* stream,
-                int64_t* num_rendered, int64_t* max_tile_entries);
+                int64_t* num_rendered, int64_t* max_tile_entries, int64_t* pair_bound, int32_t* forward_mode);
 
 /* Gradients (BACKWARD::renderCUDA backward.cu:17-532).  The six outputs must be
  * zero-filled by the caller (the reference's zeros_like, render.cu:313-318):
  * dL_dverts (P,3), dL_dverts_color (P,3), dL_dfaces_opacity (F),
  * dL_dverts_ndc (B,P,3) [only z written], dL_dfaces_intense (B,F),
- * dL_daa_face_verts (B,F,3,2). */
-int dm2_backward(const dm2_render_desc* d, int64_t num_rendered,
+ * dL_daa_face_verts (B,F,3,2).
+ * forward_mode: what the forward of this frame returned (DM2_FWD_*; DM2_FWD_UNKNOWN costs a few idle launches).
+ * tie_scratch: needed with DM2_FWD_POOL (and with DM2_FWD_UNKNOWN when the binning scratch has a pool part):
+ * dm2_scratch_bytes(DM2_SCRATCH_TIE_QUEUE, pairs of the pool part, 0) bytes, scratch of this call only.  The binning
+ * scratch is not const: the pool backward keeps its queue counters there (left as it found them). */
+int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, int32_t forward_mode,
                  const float* dL_dout_color, const float* dL_dout_depth,
                  const void* face_scratch, size_t face_bytes,
-                 const void* binning_scratch, size_t binning_bytes,
+                 void* binning_scratch, size_t binning_bytes,
                  const void* image_scratch, size_t image_bytes,
+                 void* tie_scratch, size_t tie_bytes,
                  float* dL_dverts, float* dL_dverts_color, float* dL_dfaces_opacity,
                  float* dL_dverts_ndc, float* dL_dfaces_intense, float* dL_daa_face_verts,
                  void* stream);
@@ -239,7 +263,9 @@ int dm2_debug_fetch(int what, int64_t count, int64_t aux, int64_t num_rendered,
  * pixel's (x, y) origin, unit size.  variant 0: the generic clipper of the per-pixel-walk kernels, area + Jacobian in
  * the reference's order (aa.h:151-504); 1: the forward's area-only clipper; 2: the forward's accept / reject decision,
  * then the backward's segment formulation of area + Jacobian; 3: the same with the reference's fan sum over its corners
- * (the area bit-identical to the forward's, what the backward uses for faces with opacity > 0.9).  Outputs: area (n), grad (n,3,2), code (n) int32 --
+ * (the area bit-identical to the forward's, what the exact-clipper backward uses for faces with opacity > 0.9); 4: the
+ * default backward's Jacobian without a polygon (code -1 and a zero Jacobian: the pair is a tie and takes variant 2's
+ * route; area: the forward's).  Outputs: area (n), grad (n,3,2), code (n) int32 --
  * 0 = no error, non-zero = the reference reports one of its errors E00..E05 (dmesh2_renderer/README.md; the
  * composite kernels only ever test != 0); area and grad are zero where code != 0. */
 int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, const float* aa_face_edges,

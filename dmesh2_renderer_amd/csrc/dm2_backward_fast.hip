@@ -39,14 +39,17 @@
 
 namespace dm2 {
 
-constexpr int BM_CAND = 32;      // candidate entries per chunk: two per 16-lane group of the cooperative record copy
+#ifndef DM2_BF_CAND
+#define DM2_BF_CAND 30        // 30 candidates + 127 VGPRs: four blocks per CU (40.5 KB of LDS each).  A/B at cfg4: 32 candidates / 3 blocks 1.17 ms, 30 / 4 blocks 1.05 ms, 28 / 4 blocks 1.05 ms
+#endif
+constexpr int BM_CAND = DM2_BF_CAND;      // candidate entries per chunk
 static_assert(BM_CAND * 4 <= TILE_PIX && 2 * BM_CAND <= 64, "one scan thread per (face, wave); one id window per wave");
 constexpr int BM_SLOTS = BM_CAND * 4;
-constexpr int REC_CHUNKS = (int)(sizeof(FaceRec) / 16);   // 15 x 16 B of the 256-B global record are live
+constexpr int REC_CHUNKS = FACE_RECB_PARTS;               // 12 of the 16 sixteen-byte parts of the global record (dm2_stage.h: FaceRecB)
+constexpr int REC_PER_INSTR = 64 / REC_CHUNKS;            // records one wave instruction copies
+static_assert(8 * REC_PER_INSTR >= BM_CAND, "two LDS-direct instructions per wave fetch a chunk");
 #ifndef DM2_BF_BLOCKS
-#define DM2_BF_BLOCKS 3       // resident blocks per CU the register budget is set for.  A/B at cfg4 on MI355X: 4 blocks (128 VGPRs) spill
-                              // 39 registers to scratch, and a scratch reload waits for every LDS-direct load issued before it: 2.08 ms;
-                              // 3 blocks (no spill) 1.63 ms
+#define DM2_BF_BLOCKS 4       // resident blocks per CU the register budget is set for (no spills at 127 VGPRs)
 #endif
 __global__ void __launch_bounds__(TILE_PIX, DM2_BF_BLOCKS)
 k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
@@ -59,17 +62,17 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                        TieEntry* __restrict__ tie_queue, uint32_t tie_cap, bool check_mode STAMP_PARAM) {
     if (check_mode && hit_valid[0] != 3u) return;                  // (caller did not know what the forward left: not masks + pool -> another kernel runs)
 
-    __shared__ FaceRec recs2[2][BM_CAND];                      // [buffer]: this chunk's candidates / the next chunk's
+    __shared__ FaceRecB recs2[2][BM_CAND];                     // [buffer]: this chunk's candidates / the next chunk's
     __shared__ float acc[BM_CAND * BM_ACC];
-    __shared__ BmPair s_pair[TILE_PIX];
+    __shared__ BfPair s_pair[TILE_PIX];
     __shared__ float s_ray[TILE_PIX * 6];
     __shared__ __attribute__((aligned(16))) unsigned long long s_hit2[2][BM_SLOTS];   // [buffer][face][wave]: pixels of the wave the face blends into
-    __shared__ int s_wbase[4][BM_CAND];                        // [wave][face]: pairs in front of slot (face, wave) -- written and read by that wave
-    __shared__ int s_efirst[4][BM_CAND];                       // [wave][face]: the chunk's pairs in front of the face -- written and read by that wave
+    __shared__ uint16_t s_wbase[4][BM_CAND];                        // [wave][face]: pairs in front of slot (face, wave) -- written and read by that wave
+    __shared__ uint16_t s_efirst[4][BM_CAND];                       // [wave][face]: the chunk's pairs in front of the face -- written and read by that wave
     __shared__ uint32_t s_hb2[2][BM_CAND];                     // [buffer][face]: pool slot of the entry's first blended pair
     __shared__ uint32_t s_mark[4][64];                         // [wave][pair lane]: (slot + 1) << 9 | first pair of the slot, where a slot starts
     __shared__ unsigned long long s_mask[TILE_PIX];            // per pixel: faces of the chunk with a record for it
-    __shared__ uint32_t s_ids2[2][2 * BM_CAND];                // [buffer]: face ids of the walk positions [base, base + 64)
+    __shared__ uint32_t s_ids2[2][64];                         // [buffer]: face ids of the walk positions [base, base + 64): one wave-wide request
     __shared__ float s_pixc[6][TILE_PIX];                      // per pixel, read by phase C only: dL/dcolour, dL/ddepth, final T, T in front of the last contributor
     __shared__ float* s_fl_base[32];                           // flush, per component: destination of id 0 ...
     __shared__ int s_fl_sel[32];                               // ... which id of the record (face_id, vid[0..2]) | dwords per id << 2
@@ -137,7 +140,8 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     // (backward.cu:171).  The next chunk's inputs go straight from global memory into the other LDS buffer
     // (global_load_lds: per-lane source address, destination = wave-uniform base + lane * size; no registers held).
     auto walk_entry = [&](int k) -> int64_t { return (int64_t)range.x + (uint32_t)(total - 1 - k); };
-    const int rl = lane / REC_CHUNKS, rp = lane - rl * REC_CHUNKS;   // record copy: 4 records x 15 parts per wave instruction
+    const int rl = lane / REC_CHUNKS, rp = lane - rl * REC_CHUNKS;   // record copy: 5 records x 12 parts per wave instruction
+    const int rsrc = recb_src_part(rp);
     // request the id window [nb, nb + 64) of the walk into s_ids2[buf]
     auto request_ids = [&](int buf, int nb) {
         if (wid == 2 && nb + lane < total)
@@ -153,9 +157,9 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         if (wid == 3 && lane < nc2) glds4(hit_base + walk_entry(nb + lane), &s_hb2[buf][0]);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int r0 = (i * 4 + wid) * 4;                      // this wave instruction's first record
+            const int r0 = (i * 4 + wid) * REC_PER_INSTR;          // this wave instruction's first record
             const int r = r0 + rl;
-            if (rl < 4 && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rp, &recs2[buf][r0]);
+            if (rl < REC_PER_INSTR && r < nc2) glds16(grecs + (int64_t)ids[r] * FACE_REC_U4 + rsrc, &recs2[buf][0] + r0);
         }
     };
     if (total > 0) {                                               // first chunk: synchronously
@@ -178,7 +182,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(1)
         const int nc = min(BM_CAND, total - base);
         // recs[j] / s_hit[j][.] = walk position base + j (requested by the previous chunk, or by the prologue)
-        FaceRec* const recs = recs2[cur];
+        FaceRecB* const recs = recs2[cur];
         const unsigned long long* const s_hit = s_hit2[cur];
         const uint32_t* const s_ids = s_ids2[cur];
         const uint32_t* const s_hb = s_hb2[cur];
@@ -194,8 +198,8 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // up to the end of face j
         n = max(1, __popcll(__ballot((lane & 1) && inc <= TILE_PIX && (lane >> 1) < nc)));
         const int S = __builtin_amdgcn_readlane(inc, 2 * n - 1);
-        if ((lane & 1) == (wid >> 1)) s_wbase[wid][lane >> 1] = (wid & 1) ? b1 : b0;    // phase C: slot (face, this wave)
-        if ((lane & 1) == 0) s_efirst[wid][lane >> 1] = b0;                              // B2: the face's first pair
+        if ((lane & 1) == (wid >> 1) && (lane >> 1) < BM_CAND) s_wbase[wid][lane >> 1] = (uint16_t)((wid & 1) ? b1 : b0);    // phase C: slot (face, this wave)
+        if ((lane & 1) == 0 && (lane >> 1) < BM_CAND) s_efirst[wid][lane >> 1] = (uint16_t)b0;                              // B2: the face's first pair
         // pair lane -> slot: every non-empty slot that starts inside this wave's 64 pair lanes leaves a mark at its first
         // pair; a running maximum spreads it (slots and their first pairs grow together); the slot that covers the wave's
         // first lane comes from a ballot
@@ -238,9 +242,9 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             // (backward.cu:340-348) and the background term by it once more (backward.cu:396-401), so that one ulp of alpha is
             // ulp / (1 - alpha) of both; with the forward's own number a nearly opaque, nearly covering face is no special case.
             // Pool slot: the entry's first pair + this pair's place among the entry's pairs (the pool is in mask order).
-            ratio = pool[s_hb[j] + (uint32_t)(tid - s_efirst[wid][j])];
-            const FaceRec& fc = recs[j];
-            BmPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0; out.T = 0.f; out.dL_dalpha = 0.f;
+            ratio = pool[s_hb[j] + (uint32_t)(tid - (int)s_efirst[wid][j])];
+            const FaceRecB& fc = recs[j];
+            BfPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0;
             const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
             const f3 rd = {s_ray[q * 6 + 3], s_ray[q * 6 + 4], s_ray[q * 6 + 5]};
             const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
@@ -297,12 +301,15 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 if (e >= last_contributor) continue;                              // backward.cu:219-221
                 // slot of (face jj, this pixel): hits before (jj, this wave) + hits of lower pixels of this wave
                 const int t = jj * 4 + wid;
-                BmPair& pr = s_pair[s_wbase[wid][jj] + __popcll(s_hit[t] & ((1ull << lane) - 1ull))];
+                BfPair& pr = s_pair[(int)s_wbase[wid][jj] + __popcll(s_hit[t] & ((1ull << lane) - 1ull))];
                 const float a = pr.alpha, iC0 = pr.c0, iC1 = pr.c1, iC2 = pr.c2, iD = pr.depth;
                 // alpha == 1 exactly (backward.cu:396) is the forward's decision too: only a pixel's LAST contributor can
                 // have it (T drops to 0 and the pixel is done), and then final_T is exactly 0
                 const bool alpha_is_one = (a == 1.0f) || (T_first_pass && T_final == 0.0f);
-                if (!T_first_pass) T = T / (1.f - a);                             // backward.cu:340-348
+                // (1 / (1 - alpha) once, to <= 1 ulp, for the running T and for the background term: the gradients owe the
+                // reference 1e-5, not the bits of its two IEEE divisions)
+                const float inv_1ma = rcp_refined(1.f - a);
+                if (!T_first_pass) T = T * inv_1ma;                               // backward.cu:340-348
                 T_first_pass = false;
                 float dL_dalpha = 0.0f;
                 accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = iC0;
@@ -322,12 +329,10 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     dL_dalpha += (-prev_T_final) * bg_dot;
                     dL_dalpha += (-prev_T_final) * bd_dot;
                 } else {
-                    dL_dalpha += (-T_final / (1.f - a)) * bg_dot;
-                    dL_dalpha += (-T_final / (1.f - a)) * bd_dot;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot;
+                    dL_dalpha += (-T_final * inv_1ma) * bd_dot;
                 }
-                pr.T = T; pr.dL_dalpha = dL_dalpha; pr.flags = MB_BLEND | MB_ACTIVE;
-                // phase D needs this pixel's loss gradients, not the colours any more: hand them over in place
-                pr.c0 = dLc0; pr.c1 = dLc1; pr.c2 = dLc2; pr.depth = dLd;
+                pr.depth = T; pr.alpha = dL_dalpha; pr.flags = MB_BLEND | MB_ACTIVE;   // (phase D: T, dL/dalpha in place of depth, alpha)
             }
         }
         STAMP(7)
@@ -346,15 +351,15 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const bool s4 = (l16 >= 4) & (k4 == jkey);
             const bool s8 = (l16 >= 8) & (k8 == jkey);
             const float m1 = s1 ? 1.f : 0.f, m2 = s2 ? 1.f : 0.f, m4 = s4 ? 1.f : 0.f, m8 = s8 ? 1.f : 0.f;
-            BmPair pr; pr.flags = 0; pr.T = 0.f; pr.dL_dalpha = 0.f; pr.c0 = pr.c1 = pr.c2 = pr.depth = 0.f;
-            if (have && blend) pr = s_pair[tid];
-            const bool active = (pr.flags & MB_ACTIVE) != 0;
+            uint32_t pflags = 0; float pr_T = 0.f, pr_dL_dalpha = 0.f;
+            if (have && blend) { const BfPair& pr = s_pair[tid]; pflags = pr.flags; pr_T = pr.depth; pr_dL_dalpha = pr.alpha; }
+            const bool active = (pflags & MB_ACTIVE) != 0;
             float nact = active ? 1.f : 0.f;
             seg_scan16(nact, s1, s2, s4, s8);
             const bool emit = ((l16 == 15) | (kn != jkey)) & (jkey >= 0) & (nact > 0.f);
             float* const arow = acc + j * BM_ACC;
 #if DM2_BM_CARRY < 2
-            const FaceRec& fcD = recs[j];
+            const FaceRecB& fcD = recs[j];
 #endif
             float dL_diu = 0.f, dL_div = 0.f, dL_doarea = 0.f;
             {   // group 1: vertex colours, NDC depth, intensity, opacity
@@ -362,8 +367,8 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 #pragma unroll
                 for (int c = 0; c < 14; c++) g1[c] = 0.f;
                 if (active) {
-                    const float Tq = pr.T, dL_dalpha = pr.dL_dalpha;
-                    const float qc0 = pr.c0, qc1 = pr.c1, qc2 = pr.c2, qd = pr.depth;   // dL/dcolour, dL/ddepth of the pixel
+                    const float Tq = pr_T, dL_dalpha = pr_dL_dalpha;
+                    const float qc0 = s_pixc[0][q], qc1 = s_pixc[1][q], qc2 = s_pixc[2][q], qd = s_pixc[3][q];   // dL/dcolour, dL/ddepth of the pixel
 #if DM2_BM_CARRY > 1
                     const float intense = k_int, opacity = k_opa;
                     const float* const colD = k_col; const float* const depD = k_dep;
@@ -398,7 +403,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
                     dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
                 }
-                seg_scan16_n(g1, m1, m2, m4, m8);
+                seg_scan16_safe(g1, m1, m2, m4, m8, s1, s2, s4, s8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 12; c++) atomicAdd(arow + M_DC + c, g1[c]);      // M_DC..+8 and M_DZ..+2 are contiguous
@@ -417,7 +422,8 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 float g2[6];
                 bool tie = false;
                 {
-                    const AAFace& fa = recs[j].aa;
+                    const FaceRecB& fb = recs[j];
+                    const AAFaceB fa = {fb.v2, fb.e, fb.r, fb.zmask};
                     const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pymin = (float)(uint32_t)(Y0a + (q >> 4));
                     fast_area_grad(fa, pxmin, pxmin + 1, pymin, pymin + 1, g2, tie);
                 }
@@ -427,7 +433,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 for (int c = 0; c < 6; c++) g2[c] = use ? dL_doarea * g2[c] : 0.0f;     // (a select: a tie's or an idle lane's entries need not be finite)
                 tie_bal = __ballot(tie_push);
                 if (tie_bal && lane == (int)(__ffsll((long long)tie_bal) - 1)) tie_base = atomicAdd(hit_valid + 2, (uint32_t)__popcll(tie_bal));
-                seg_scan16_n(g2, m1, m2, m4, m8);
+                seg_scan16_safe(g2, m1, m2, m4, m8, s1, s2, s4, s8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 6; c++) atomicAdd(arow + M_AA + c, g2[c]);
@@ -446,7 +452,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     const f3 p0 = {fcD.v[0], fcD.v[1], fcD.v[2]}, p1 = {fcD.v[3], fcD.v[4], fcD.v[5]}, p2 = {fcD.v[6], fcD.v[7], fcD.v[8]};
 #endif
                     f3 du0, du1, du2, dv0, dv1, dv2;
-                    ray_tri_intersection_grad(ro, rd, p0, p1, p2, corrected, du0, du1, du2, dv0, dv1, dv2);
+                    ray_tri_intersection_grad<true>(ro, rd, p0, p1, p2, corrected, du0, du1, du2, dv0, dv1, dv2);
                     const f3 dp0 = dL_diu * du0 + dL_div * dv0;
                     const f3 dp1 = dL_diu * du1 + dL_div * dv1;
                     const f3 dp2 = dL_diu * du2 + dL_div * dv2;
@@ -454,7 +460,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     g3[3] = dp1.x; g3[4] = dp1.y; g3[5] = dp1.z;
                     g3[6] = dp2.x; g3[7] = dp2.y; g3[8] = dp2.z;
                 }
-                seg_scan16_n(g3, m1, m2, m4, m8);
+                seg_scan16_safe(g3, m1, m2, m4, m8, s1, s2, s4, s8);
                 if (emit) {
 #pragma unroll
                     for (int c = 0; c < 9; c++) atomicAdd(arow + M_DV + c, g3[c]);
@@ -486,7 +492,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 const float flag = a[M_FLAG];                                     // (the 32 lanes of an entry sit in one wave)
                 const float val = a[comp];
                 int sel = sel0;
-                if (corner) { int m_; flush_id_and_mult(entry, recs[e].aa.zmask, sel, m_); }   // (the record knows the reorder)
+                if (corner) { int m_; flush_id_and_mult(entry, recs[e].zmask, sel, m_); }      // (the record knows the reorder)
                 const int id = (&recs[e].face_id)[sel];
                 if (flag != 0.f) {
                     a[comp] = 0.f;                                                // ready for the next chunk

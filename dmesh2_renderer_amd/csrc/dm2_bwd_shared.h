@@ -18,6 +18,10 @@ constexpr uint32_t MB_BLEND = 1u, MB_ACTIVE = 2u;
 
 struct __attribute__((aligned(16))) BmPair { float alpha, c0, c1, c2, depth; uint32_t flags; float T, dL_dalpha; };
 static_assert(sizeof(BmPair) == 32, "BmPair");
+// dm2_backward_fast.hip: phase B2 leaves (alpha, colour, depth), phase C replaces alpha by dL/dalpha and depth by the T in
+// front of the pair and sets the flags; phase D reads the pixel's loss gradients from the per-pixel LDS rows itself
+struct __attribute__((aligned(8))) BfPair { float alpha, c0, c1, c2, depth; uint32_t flags; };
+static_assert(sizeof(BfPair) == 24, "BfPair");
 
 // index of the n-th (0-based) set bit of m; n < popcount(m)
 __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n) {

@@ -11,7 +11,7 @@
 //     the pixel line's constant and p0o + t * eo) or the end point itself -- and D = E - S;
 //   * a crossing on a y = const line carries the weight 1/2 D.y on its computed x, one on an x = const line -1/2 D.x on
 //     its computed y (its polygon neighbour on the far side lies on the same pixel line), pushed through the
-//     reference's Jacobian of the crossing (t, 1 - t, gt0, gt1 as written at aa.h:276-294);
+//     reference's Jacobian of the crossing (aa.h:276-294: t, 1 - t and dt/dp = -(1 - t) / e, -t / e);
 //   * an end point inside the pixel carries 1/2 (D.y, -D.x) from each of its two edges.
 //
 // Same polynomial in the same corner coordinates as the reference's, hence the same fp32 rounding of the corner
@@ -32,11 +32,11 @@ namespace dm2 {
 
 // margin of the tie tests: 2^-19 of the larger pixel coordinate = 16..32 ulp of an image coordinate there
 constexpr float FAST_TIE_REL = 1.0f / 524288.0f;
-constexpr float FAST_TIE_ISZERO = 1.5e-3f;          // with an "iszero" edge in the face: both ends of such an edge lie within 1e-3 of a line it straddles
+constexpr float FAST_TIE_ISZERO = 1.5e-3f;          // both ends of an "iszero" edge lie within 1e-3 of a line it straddles
 
-template <int TI>
-__device__ __forceinline__ void fast_edge(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax,
-                                          float delta_v, float delta_c, float* g, bool& tie) {
+template <int TI, class Face>      // Face: anything with v[6], e[6], r[6], zmask (AAFace, or the backward's shorter LDS record)
+__device__ __forceinline__ void fast_edge(const Face& f, float pxmin, float pxmax, float pymin, float pymax,
+                                          float delta, float* g, bool& tie) {
     constexpr int TJ = (TI + 1) % 3;
     const float p0x = f.v[2 * TI], p0y = f.v[2 * TI + 1], p1x = f.v[2 * TJ], p1y = f.v[2 * TJ + 1];
     const float ex = f.e[2 * TI], ey = f.e[2 * TI + 1], rx = f.r[2 * TI], ry = f.r[2 * TI + 1];
@@ -45,8 +45,11 @@ __device__ __forceinline__ void fast_edge(const AAFace& f, float pxmin, float px
     const float tD = dxl * rx, tB = dxh * rx, tA = dyl * ry, tC = dyh * ry;
     const bool cx = tD < tB, cy = tA < tC;
     const float xlo = fminf(tD, tB), xhi = fmaxf(tD, tB), ylo = fminf(tA, tC), yhi = fmaxf(tA, tC);
-    const float ts = fmaxf(fmaxf(xlo, ylo), 0.0f), te = fminf(fminf(xhi, yhi), 1.0f);
-    const bool on = te > ts;                                          // the edge has a piece inside the pixel
+    const float ts_ = fmaxf(fmaxf(xlo, ylo), 0.0f), te_ = fminf(fminf(xhi, yhi), 1.0f);
+    const bool on = te_ > ts_;                                        // the edge has a piece inside the pixel
+    // (an edge with no piece inside contributes through operands set to 0: the reciprocal of an axis-parallel edge is
+    // infinite and its crossing parameters with it, and 0 * inf must not reach g)
+    const float ts = on ? ts_ : 0.0f, te = on ? te_ : 1.0f;
     const bool sV = !(ts > 0.0f), eV = !(te < 1.0f);                  // that piece starts at p0 / ends at p1
     const bool sX = (xlo > ylo) && !sV, eX = (xhi < yhi) && !eV;      // ... at a crossing of an x = const line (else y = const)
     const float wxlo = cx ? pxmin : pxmax, wxhi = cx ? pxmax : pxmin;
@@ -55,46 +58,51 @@ __device__ __forceinline__ void fast_edge(const AAFace& f, float pxmin, float px
     const float Sx = sX ? wxlo : p0x + ts * ex, Sy = (!sX && !sV) ? wylo : p0y + ts * ey;
     const float Ex = eV ? p1x : (eX ? wxhi : p0x + te * ex), Ey = eV ? p1y : (eX ? p0y + te * ey : wyhi);
     const float Dx = Ex - Sx, Dy = Ey - Sy;
-    const float hx = on ? 0.5f * Dy : 0.0f, hy = on ? -(0.5f * Dx) : 0.0f;     // 1/2 (D.y, -D.x); 0: nothing below contributes
-    // end points inside the pixel: identity Jacobian
-    g[2 * TI] += sV ? hx : 0.0f; g[2 * TI + 1] += sV ? hy : 0.0f;
-    g[2 * TJ] += eV ? hx : 0.0f; g[2 * TJ + 1] += eV ? hy : 0.0f;
-    // crossings: computed coordinate m = p0o + t * eo on the line a = w; dm/dp0 = (1 - t [o], gt0 * eo [a]), dm/dp1 = (t, gt1 * eo)
-    // (a corner that is not a crossing, or an edge with no piece inside, contributes through operands set to 0: the
-    // reciprocal of an axis-parallel edge is infinite and its crossing parameters with it, and 0 * inf must not reach g)
-    auto crossing = [&](bool isX, bool isV, float t_, float wx, float wy) {
-        const bool c = on && !isV;
-        const float w = isX ? wx : wy, p0a = isX ? p0x : p0y, p1a = isX ? p1x : p1y;
-        const float ra = c ? (isX ? rx : ry) : 0.0f, t = c ? t_ : 0.0f;
-        const float eo = isX ? ey : ex;
-        const float gm = c ? (isX ? hy : hx) : 0.0f;
-        const float gt0 = (w - p1a) * ra * ra, gt1 = (-w + p0a) * ra * ra;      // aa.h:276-294
-        const float omt = 1.0f - t;
-        const float a_o = omt * gm, a_a = (gt0 * eo) * gm, b_o = t * gm, b_a = (gt1 * eo) * gm;
-        g[2 * TI] += isX ? a_a : a_o; g[2 * TI + 1] += isX ? a_o : a_a;
-        g[2 * TJ] += isX ? b_a : b_o; g[2 * TJ + 1] += isX ? b_o : b_a;
-    };
-    crossing(sX, sV, ts, wxlo, wylo);
-    crossing(eX, eV, te, wxhi, wyhi);
-    // ties: the corner p0 within delta_v of one of the four pixel lines; the edge's line within ~delta_c of a pixel corner
-    // (there the crossings with the two lines through that corner have the same parameter; the distance along the edge)
-    const float m2 = fminf(fminf(fabsf(dxl), fabsf(dxh)), fminf(fabsf(dyl), fabsf(dyh)));
-    const float m3 = fminf(fminf(fabsf(tA - tB), fabsf(tB - tC)), fminf(fabsf(tC - tD), fabsf(tD - tA)));
+    const float hx = on ? 0.5f * Dy : 0.0f, hy = on ? -(0.5f * Dx) : 0.0f;     // 1/2 (D.y, -D.x)
+    // A corner at parameter t gives p0 (1 - t) V and p1 t V, with V = 1/2 (D.y, -D.x) for an end point (t = 0 or 1: identity
+    // Jacobian), V = 1/2 D.y (1, -e.x / e.y) for a crossing of a y = const line (its x = p0x + t e.x moves, weight 1/2 D.y;
+    // dt/dp0y = -(1 - t) / e.y, dt/dp1y = -t / e.y: aa.h:276-294 up to the rounding of one factor), V = -1/2 D.x (-e.y / e.x, 1)
+    // for a crossing of an x = const line.
+    const float kx = on ? ex * ry : 0.0f, ky = on ? ey * rx : 0.0f;
+    const float vyy = -(kx * hx), vxx = -(ky * hy);
+    const float Vsx = sV ? hx : (sX ? vxx : hx), Vsy = sV ? hy : (sX ? hy : vyy);
+    const float Vex = eV ? hx : (eX ? vxx : hx), Vey = eV ? hy : (eX ? hy : vyy);
+    const float oms = 1.0f - ts, ome = 1.0f - te;
+    g[2 * TI] += oms * Vsx + ome * Vex; g[2 * TI + 1] += oms * Vsy + ome * Vey;
+    g[2 * TJ] += ts * Vsx + te * Vex; g[2 * TJ + 1] += ts * Vsy + te * Vey;
+    // ---- ties (see the header).  (a) the corner p0 within delta of a pixel line while inside the other slab widened by delta
+    const float ax = fminf(fabsf(dxl), fabsf(dxh)), ay = fminf(fabsf(dyl), fabsf(dyh));
+    const bool inx = (dxl <= delta) && (dxh >= -delta), iny = (dyl <= delta) && (dyh >= -delta);
+    tie = tie || (!(ax >= delta) && iny) || (!(ay >= delta) && inx);
+    // (b) an "iszero" edge (|e| < 1e-3 on an axis: the reference ignores its crossings with the pixel lines of that axis,
+    // pyrenderer.py:14) one of whose ends is within 1.5e-3 of such a line: it may straddle it
+    const uint32_t zx = (f.zmask >> (2 * TI)) & 1u, zy = (f.zmask >> (2 * TI + 1)) & 1u;
+    if (zx | zy) {                                                     // (rare: one face in a few hundred)
+        const float bx = fminf(fabsf(pxmin - p1x), fabsf(pxmax - p1x)), by = fminf(fabsf(pymin - p1y), fabsf(pymax - p1y));
+        tie = tie || (zx && !(fminf(ax, bx) >= FAST_TIE_ISZERO)) || (zy && !(fminf(ay, by) >= FAST_TIE_ISZERO));
+    }
+    // (c) the edge's line within ~delta of a pixel corner that lies on the edge: the crossings with the two pixel lines
+    // through that corner then have (nearly) the same parameter, inside [0, 1] widened by delta / |e|
     const float emax = fmaxf(fabsf(ex), fabsf(ey));
-    tie = tie || !(m2 >= delta_v) || !(m3 * emax >= delta_c);         // (NaN -- 0 * inf of a degenerate edge -- counts as a tie)
+    const float tt = delta * __builtin_amdgcn_rcpf(emax), thi = 1.0f + tt;     // (a margin: v_rcp_f32's ulp does not matter)
+    const bool cAB = !(fabsf(tA - tB) * emax >= delta) && (tA >= -tt) && (tA <= thi);
+    const bool cBC = !(fabsf(tB - tC) * emax >= delta) && (tB >= -tt) && (tB <= thi);
+    const bool cCD = !(fabsf(tC - tD) * emax >= delta) && (tC >= -tt) && (tC <= thi);
+    const bool cDA = !(fabsf(tD - tA) * emax >= delta) && (tD >= -tt) && (tD <= thi);
+    tie = tie || cAB || cBC || cCD || cDA;
 }
 
 // g: [3][2] row-major, d(area)/d(aa_face_verts) of the pair.  tie: the pair needs the exact clipper instead (g is then
 // meaningless and must not be used).
-__device__ __forceinline__ void fast_area_grad(const AAFace& f, float pxmin, float pxmax, float pymin, float pymax, float* g, bool& tie) {
+template <class Face>
+__device__ __forceinline__ void fast_area_grad(const Face& f, float pxmin, float pxmax, float pymin, float pymax, float* g, bool& tie) {
 #pragma unroll
     for (int k = 0; k < 6; k++) g[k] = 0.f;
-    const float delta_c = fmaxf(pxmax, pymax) * FAST_TIE_REL;
-    const float delta_v = (f.zmask & 0x3Fu) ? fmaxf(delta_c, FAST_TIE_ISZERO) : delta_c;
+    const float delta = fmaxf(pxmax, pymax) * FAST_TIE_REL;
     tie = false;
-    fast_edge<0>(f, pxmin, pxmax, pymin, pymax, delta_v, delta_c, g, tie);
-    fast_edge<1>(f, pxmin, pxmax, pymin, pymax, delta_v, delta_c, g, tie);
-    fast_edge<2>(f, pxmin, pxmax, pymin, pymax, delta_v, delta_c, g, tie);
+    fast_edge<0>(f, pxmin, pxmax, pymin, pymax, delta, g, tie);
+    fast_edge<1>(f, pxmin, pxmax, pymin, pymax, delta, g, tie);
+    fast_edge<2>(f, pxmin, pxmax, pymin, pymax, delta, g, tie);
     // a non-finite entry (a degenerate face) never passes for a result
     tie = tie || !(fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2]) + fabsf(g[3]) + fabsf(g[4]) + fabsf(g[5]) < 3.0e38f);
 }

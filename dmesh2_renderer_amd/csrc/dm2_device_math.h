@@ -63,6 +63,14 @@ __device__ __forceinline__ bool ray_tri_intersection(f3 ro, f3 rd, f3 p0, f3 p1,
 
 // ---- auxiliary.h:245-290.  As written the "dv" outputs are grad(t), not grad(v);
 // corrected=true computes the true grad(v) (opt-in flag DM2_FLAG_CORRECTED_DV).
+// 1 / x to <= 1 ulp without the IEEE division's ~19 instructions (v_rcp_f32 + one Newton step): for gradient terms, which owe
+// the reference 1e-5, not its bits
+__device__ __forceinline__ float rcp_refined(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
+template <bool FAST_RCP = false>
 __device__ __forceinline__ void ray_tri_intersection_grad(f3 ro, f3 rd, f3 p0, f3 p1, f3 p2, bool corrected,
                                                           f3& du_dp0, f3& du_dp1, f3& du_dp2,
                                                           f3& dv_dp0, f3& dv_dp1, f3& dv_dp2) {
@@ -70,7 +78,7 @@ __device__ __forceinline__ void ray_tri_intersection_grad(f3 ro, f3 rd, f3 p0, f
     f3 dxE2 = cross(rd, E2);
     float denom_sqrt = dot(dxE2, E1);
     float denom = denom_sqrt * denom_sqrt;
-    float denom_inv = 1.0f / denom;          // the reference clamps denom AFTER this (dead clamp)
+    float denom_inv = FAST_RCP ? rcp_refined(denom) : 1.0f / denom;          // the reference clamps denom AFTER this (dead clamp)
     float v0 = dot(dxE2, T);
     float v1 = denom_sqrt;
     f3 E1xd = cross(E1, rd);
@@ -149,15 +157,16 @@ __device__ __forceinline__ void patch_rect_from_tri(uint32_t pmx, uint32_t pmy, 
 // AA: overlap area of a CCW triangle with a unit pixel, + d(area)/d(tri verts)
 // (aa.h:15-504).  Per-face tables as the caller staged them (LDS or registers).
 // =============================================================================
-struct AAFace {
+struct AAFace {    // (member order: what the default backward reads -- v, e, r, zmask -- fills the record's first five 16-byte parts)
     float v[6];     // aa_face_verts        [3][2]
     float e[6];     // aa_face_edges        [3][2]
     float r[6];     // aa_face_edges_recip  [3][2]
-    float n[6];     // aa_face_edges_normal [3][2]
-    float c[3];     // aa_face_edges_normal_c
     uint32_t zmask; // bit (2*i+k) = aa_face_edges_iszero[i][k]
+    float c[3];     // aa_face_edges_normal_c
+    float n[6];     // aa_face_edges_normal [3][2]
     float bb[4];    // txmin, txmax, tymin, tymax  (aa_face_verts.min/max over corners, forward.cu:480-481)
 };
+static_assert(sizeof(AAFace) == 128, "AAFace: 32 dwords");
 
 struct PolyVert {   // one vertex of the clipped polygon and its Jacobians w.r.t. the
     float x, y;     // two end points (i0, i0+1 mod 3) of triangle edge `idx` (-1: pixel corner)

@@ -38,4 +38,18 @@ __device__ __forceinline__ void seg_scan16_n(float (&g)[N], float m1, float m2, 
     for (int c = 0; c < N; c++) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(g[c]) : "v"(m8));
 }
 
+// seg_scan16_n for values that may not be finite (a sliver face whose determinant underflows, a NaN vertex): the
+// multiply-by-0 continuation mask of the fast form would turn a neighbouring run's Inf into NaN in THIS run, so a wave in
+// which any lane holds a non-finite value takes the select form (two instructions per value and step), which keeps a
+// non-finite gradient inside the rows of the face that produced it, as the reference's per-pair atomics do.
+template <int N>
+__device__ __forceinline__ void seg_scan16_safe(float (&g)[N], float m1, float m2, float m4, float m8, bool s1, bool s2, bool s4, bool s8) {
+    float mag = 0.f;
+#pragma unroll
+    for (int c = 0; c < N; c++) mag += fabsf(g[c]);
+    if (__builtin_expect(__ballot(!(mag < 3.0e38f)) == 0ull, 1)) { seg_scan16_n(g, m1, m2, m4, m8); return; }
+#pragma unroll
+    for (int c = 0; c < N; c++) seg_scan16(g[c], s1, s2, s4, s8);
+}
+
 }  // namespace dm2

@@ -52,6 +52,7 @@ static_assert(FQ_CHUNK <= 64, "one mask bit per staged face; the id window is on
 constexpr int FQ_REC_CHUNKS = (int)(sizeof(FaceRec) / 16);
 static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
 static_assert(FQ_PAIRCAP < 65536, "16-bit slots");
+static_assert(FQ_SURVCAP <= 2 * TILE_PIX, "phase B2 runs at most two rounds");
 
 constexpr uint32_t QF_REC = 1u;      // AA overlap found (the reference takes an AA record here)
 constexpr uint32_t QF_BLEND = 2u;    // the face blends into the pixel
@@ -77,7 +78,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ uint32_t s_queue[4 * FQ_QCAP];            // survivors: q | face << 8 | corner mask << 14
     __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
     __shared__ __attribute__((aligned(16))) unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
-    __shared__ uint16_t s_ebase[4][FQ_CHUNK];            // [wave][face]: blended pairs of the chunk in front of the face (every wave scans for itself)
+    __shared__ __attribute__((aligned(16))) uint32_t s_rcnt[8];  // [round][wave]: blending survivors of that wave's lanes in that B2 round
     __shared__ uint32_t s_cbase;                         // pair pool: first slot of this chunk
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -234,11 +235,22 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         uint32_t cbase = 0;
         if (pool && tid == 0) cbase = atomicAdd(hit_valid + 1, (uint32_t)S);
         // ---- phase B2: one survivor per lane ------------------------------------------------
-        for (int s = tid; s < S; s += TILE_PIX) {
+        // (at most two rounds of 256 survivors: SURVCAP.  Pool: a blending survivor's slot is the chunk's first slot + its rank
+        // among the chunk's blending survivors -- survivor order is (entry, pixel) order, the order of the masks -- taken with a
+        // ballot per wave and round and completed behind the barrier)
+        float pool_ratio[2] = {0.f, 0.f};
+        int pool_rank[2] = {-1, -1};
+        if (pool && lane == 0) s_rcnt[4 + wid] = 0;   // (a second round that does not run; the barrier behind B1 separates this from the last chunk's readers)
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int s = tid + rnd * TILE_PIX;
+            if (rnd == 1 && S <= TILE_PIX) break;                   // (block-uniform)
+            bool blend_s = false;
+            float ratio_s = 0.f;
+            if (s < S) {
             const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
             const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
-            uint32_t* const qslot = &s_queue[w * FQ_QCAP + (s - wb)];
-            const uint32_t entry = *qslot;
+            const uint32_t entry = s_queue[w * FQ_QCAP + (s - wb)];
             const int q = (int)(entry & 255u), j = (int)((entry >> 8) & 63u);
             const uint32_t cmask = entry >> 14;
             const FaceRec& fc = recs[j];
@@ -270,8 +282,8 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                         out.c0 = c0 * fc.intense; out.c1 = c1 * fc.intense; out.c2 = c2 * fc.intense;
                         out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
                         out.alpha = fc.opacity * ratio;
-                        out.flags |= QF_BLEND | ((uint32_t)q << 8) | ((uint32_t)j << 16);
-                        *qslot = __float_as_uint(ratio);              // (the queue entry is spent: it keeps the coverage for the pool)
+                        out.flags |= QF_BLEND;
+                        blend_s = true; ratio_s = ratio;
                     }
                 }
             }
@@ -279,7 +291,14 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 s_pair[s] = out;
                 atomicOr(&s_mask[q], 1ull << j);
                 if (hit_masks && (out.flags & QF_BLEND)) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
-            } else if (pool) s_pair[s].flags = 0;                     // (the pool pass below looks at every survivor's record)
+            }
+            }
+            if (pool) {                                                 // (block-uniform; every lane of the wave is here)
+                const unsigned long long bal = __ballot(blend_s);
+                pool_ratio[rnd] = ratio_s;
+                pool_rank[rnd] = blend_s ? (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) : -1;
+                if (lane == 0) s_rcnt[rnd * 4 + wid] = __popcll(bal);
+            }
         }
         STAMP(5)
         if (pool && tid == 0) s_cbase = cbase;
@@ -291,32 +310,23 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         if (hit_masks && tid < n * 4) hit_masks[((int64_t)range.x + base + (tid >> 2)) * 4 + (tid & 3)] = s_bmask[tid];
         // ... and (dm2_backward_fast.hip) the coverage of every such pair, so that the backward neither clips for an area nor
         // depends on reproducing it: pool slots in mask order -- entry by entry, wave by wave, pixel by pixel -- behind the
-        // chunk's first slot; per entry the slot of its first pair.  Every wave scans the entries' pair counts for itself.
+        // chunk's first slot; per entry the slot of its first pair.
         if (pool) {
-            int cj = 0;
-            if (lane < n) {
-                const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane], m23 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane + 1];
-                cj = __popcll(m01.x) + __popcll(m01.y) + __popcll(m23.x) + __popcll(m23.y);
-            }
-            const int ex = wave_inclusive_scan(cj) - cj;
             const uint32_t cb = s_cbase;
-            uint16_t* const erow = s_ebase[wid];
-            if (lane < FQ_CHUNK) erow[lane] = (uint16_t)ex;
-            if (wid == 0 && lane < n) hit_base[(int64_t)range.x + base + lane] = cb + (uint32_t)ex;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // (the lanes of the wave talk through erow with no barrier in between)
-            for (int s = tid; s < S; s += TILE_PIX) {
-                const uint32_t fl = s_pair[s].flags;
-                if (!(fl & QF_BLEND)) continue;
-                const int q = (int)((fl >> 8) & 255u), j = (int)((fl >> 16) & 63u), pw = q >> 6;
-                const unsigned long long* const mj = &s_bmask[j * 4];
-                int before = (int)erow[j];
-                before += (pw > 0 ? __popcll(mj[0]) : 0) + (pw > 1 ? __popcll(mj[1]) : 0) + (pw > 2 ? __popcll(mj[2]) : 0);
-                before += __popcll(mj[pw] & ((1ull << (q & 63)) - 1ull));
-                const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
-                const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
-                const uint32_t slot = cb + (uint32_t)before;
-                if (slot < pool_cap) pool[slot] = __uint_as_float(s_queue[w * FQ_QCAP + (s - wb)]);
+            if (wid == 0) {
+                int cj = 0;
+                if (lane < n) {
+                    const ulonglong2 m01 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane], m23 = reinterpret_cast<const ulonglong2*>(s_bmask)[2 * lane + 1];
+                    cj = __popcll(m01.x) + __popcll(m01.y) + __popcll(m23.x) + __popcll(m23.y);
+                }
+                const int ex = wave_inclusive_scan(cj) - cj;
+                if (lane < n) hit_base[(int64_t)range.x + base + lane] = cb + (uint32_t)ex;
             }
+            const uint4 c03 = reinterpret_cast<const uint4*>(s_rcnt)[0], c47 = reinterpret_cast<const uint4*>(s_rcnt)[1];
+            const uint32_t r0 = (wid > 0 ? c03.x : 0u) + (wid > 1 ? c03.y : 0u) + (wid > 2 ? c03.z : 0u);
+            const uint32_t r1 = c03.x + c03.y + c03.z + c03.w + (wid > 0 ? c47.x : 0u) + (wid > 1 ? c47.y : 0u) + (wid > 2 ? c47.z : 0u);
+            if (pool_rank[0] >= 0) { const uint32_t slot = cb + r0 + (uint32_t)pool_rank[0]; if (slot < pool_cap) pool[slot] = pool_ratio[0]; }
+            if (pool_rank[1] >= 0) { const uint32_t slot = cb + r1 + (uint32_t)pool_rank[1]; if (slot < pool_cap) pool[slot] = pool_ratio[1]; }
         }
 
         // ---- phase C: ordered blend of this pixel's records ---------------------------------

@@ -29,6 +29,28 @@ struct __attribute__((aligned(16))) FaceRec {
 };
 static_assert(sizeof(FaceRec) == 236 + 4 * DM2_FACEREC_PAD && sizeof(FaceRec) % 16 == 0, "FaceRec layout");
 
+// The default backward's shorter LDS record: of the AA tables only corners, edges, reciprocals and the edge flags (parts 0-4
+// of the global record; the normals, their offsets and the bbox serve the forward's classification only), then world
+// corners ... vertex ids (parts 8-14): 12 of the 16 sixteen-byte parts, 192 bytes.
+struct __attribute__((aligned(16))) FaceRecB {
+    float v2[6], e[6], r[6];   // aa_face_verts / edges / recip  (named v2: `v` are the world-space corners below)
+    uint32_t zmask;
+    float c0_unused;
+    float v[9];         // world-space corners
+    float col[9];
+    float dep[3];
+    float opacity, intense;
+    int face_id;
+    int vid[3];
+    float pad;
+};
+static_assert(sizeof(FaceRecB) == 192, "FaceRecB layout");
+constexpr int FACE_RECB_PARTS = 12;
+// global part (16 B) of the packed record that holds part rp of a FaceRecB
+__device__ __forceinline__ int recb_src_part(int rp) { return rp < 5 ? rp : rp + 3; }
+// view of a FaceRecB's AA members under the names dm2_clip_fast.h uses
+struct AAFaceB { const float* v; const float* e; const float* r; uint32_t zmask; };
+
 // Copy the packed record of (view, face) `bf` into LDS (one lane per record: 15 loads of 16 bytes from two 128-byte
 // lines; the kernels with a prefetch pipeline copy cooperatively instead, 16 lanes per record).
 __device__ __forceinline__ void stage_face(const uint4* __restrict__ recs, int64_t bf, FaceRec& r) {

@@ -78,7 +78,8 @@ def build_inputs(cfg, device, rank, world):
         z = torch.zeros((0,), device=device)
         return 0, torch.zeros((B, H, W, 3), device=device), torch.zeros((B, H, W), device=device), z, z, z, z, z, z, z
 
-    r = dm2.Renderer(sc.mv, sc.proj, W, H, device, aa_grad_buffer_size=20)
+    # (the 21 arguments of the reference's boundary as they are: the six AA tables materialised, not built inside the op)
+    r = dm2.Renderer(sc.mv, sc.proj, W, H, device, aa_grad_buffer_size=20, tables_from_image=False)
     _C.render_forward_cuda = capture
     try:
         with torch.no_grad():
@@ -244,13 +245,44 @@ VALU_PEAK_GINSTR_PER_S_PER_SIMD = 1.05   # measured on this part (tools/calib/va
                                          # (one wave alone: 0.48; v_fma 0.83; DPP / v_min3 / v_bcnt 0.57; IEEE fp32 divide 0.056)
 
 
+def _visible_gpus():
+    """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs), without touching the HIP runtime;
+    None when sysfs does not say (the ranks then find out themselves)."""
+    import glob
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if seen and vis:
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n if seen else None
+
+
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel sources of the loaded library: counters recorded under profiles/ are only
+    quoted for the very sources they were measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dmesh2_renderer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(ROOT, "include", "dm2_hip.h")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def self_launch(opt, argv):
     """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process group (torch.distributed.run) before
     this process has touched the GPU, pass its output through and exit with its code."""
     import socket
     import subprocess
-    ndev = torch.cuda.device_count()                       # does not initialise the GPU runtime
-    if opt.gpus > ndev and os.environ.get("DM2_BENCH_SINGLE_DEVICE") != "1":
+    ndev = _visible_gpus()                                 # from sysfs: this parent never calls into HIP
+    if ndev is not None and opt.gpus > ndev and os.environ.get("DM2_BENCH_SINGLE_DEVICE") != "1":
         raise SystemExit(f"bench.py --gpus {opt.gpus}: only {ndev} GPU(s) visible (DM2_BENCH_SINGLE_DEVICE=1 rehearses N ranks on one)")
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}",
@@ -423,19 +455,24 @@ def main():
     dom = max(("forward_composite", "backward_composite"), key=lambda k: stage_ms.get(k, 0.0))
     dom_ms = stage_ms.get(dom, 0.0)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    kname = "k_render_backward_mask" if dom == "backward_composite" else "k_render_forward_queue"
+    fwd_mode = getattr(op.fwd[8], "_dm2_fwd_mode", None) if op.fwd is not None else None
+    bwd_kernel = {_C.FWD_POOL: "k_render_backward_fast", _C.FWD_MASKS: "k_render_backward_mask"}.get(fwd_mode, "k_render_backward")
+    if AA_TEMPERATURE == 0.0:
+        bwd_kernel = "k_render_backward_point"
+    kname = bwd_kernel if dom == "backward_composite" else ("k_render_forward_queue" if AA_TEMPERATURE > 0.0 else "k_render_forward_point")
     traffic, traffic_src, valu_util, valu_note = None, None, None, None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same kernel + config only
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if tj.get("config") == opt.config and world == 1 and AA_TEMPERATURE == 1.0 and kname in tj:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        # (only for the sources the counters were measured on: a changed kernel must not quote stale counters)
+        if tj.get("config") == opt.config and tj.get("csrc_sha16") == csrc_digest() and world == 1 and AA_TEMPERATURE == 1.0 and kname in tj:
             # gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide coalesced reads (MI355X_MICROARCH.md, HBM/rocprofv3);
             # both readings are kept in the json, the corrected one is reported here
             traffic = int(tj[kname]["hbm_bytes_corrected"])
             if "sq_insts_valu" in tj[kname] and dom_ms > 0:
                 valu_util = tj[kname]["sq_insts_valu"] / (1024 * VALU_PEAK_GINSTR_PER_S_PER_SIMD * 1e9 * dom_ms * 1e-3)
-                valu_note = (f"SQ_INSTS_VALU {tj[kname]['sq_insts_valu']:.4g} per launch (profiles/r02_traffic.json) / (1024 SIMDs x "
+                valu_note = (f"SQ_INSTS_VALU {tj[kname]['sq_insts_valu']:.4g} per launch (profiles/r03_traffic.json) / (1024 SIMDs x "
                              f"{VALU_PEAK_GINSTR_PER_S_PER_SIMD} G wave-instr/s measured by tools/calib/valu_calib.hip x launch time)")
-            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)"
+            traffic_src = "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; sources " + tj["csrc_sha16"] + ")"
     except (OSError, ValueError, KeyError):
         pass
     roofline = {

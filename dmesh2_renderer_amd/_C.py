@@ -31,6 +31,7 @@ DM2_FLAG_LEGACY_KERNELS = 2
 DM2_FLAG_NO_BACKWARD = 4
 DM2_FLAG_ANALYTIC_RAYS = 8
 DM2_FLAG_AA_GRAD_TO_VERTS = 16
+DM2_FLAG_TABLES_FROM_IMAGE = 32
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS, SCRATCH_PAIR_POOL, SCRATCH_TIE_QUEUE = range(7)
 # what a forward left for its backward (include/dm2_hip.h DM2_FWD_*)
 FWD_UNKNOWN, FWD_NONE, FWD_MASKS, FWD_POOL = 0, 1, 2, 3
@@ -97,7 +98,7 @@ EXPORTS = {
     "dm2_debug_stamps": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]),
 }
 
-STAGE_NAMES = ["preprocess_scan", "bin_scatter", "tile_sort", "tile_ranges", "forward_composite", "backward_composite"]
+STAGE_NAMES = ["preprocess_scan", "bin_scatter", "tile_sort", "tile_ranges", "forward_composite", "backward_composite", "backward_ties"]
 
 
 def profile_enable(on: bool):
@@ -219,10 +220,12 @@ def _make_desc(args, keep):
             raise RuntimeError(f"{nm} has shape {tuple(t.shape)}, expected {tuple(shape)}")
     need(patch_min, (B, 2), "patch_min"); need(verts_color, (P, 3), "verts_color"); need(verts_ndc, (B, P, 3), "verts_ndc")
     need(verts_image, (B, P, 2), "verts_image"); need(faces_intense, (B, F), "faces_intense")
-    for t, nm in ((aa_v, "aa_face_verts"), (aa_e, "aa_face_edges"), (aa_z, "aa_face_edges_iszero"),
-                  (aa_r, "aa_face_edges_recip"), (aa_n, "aa_face_edges_normal")):
-        need(t, (B, F, 3, 2), nm)
-    need(aa_c, (B, F, 3), "aa_face_edges_normal_c")
+    from_image = bool(getattr(_tls, "tables_from_image", False))
+    if not from_image:
+        for t, nm in ((aa_v, "aa_face_verts"), (aa_e, "aa_face_edges"), (aa_z, "aa_face_edges_iszero"),
+                      (aa_r, "aa_face_edges_recip"), (aa_n, "aa_face_edges_normal")):
+            need(t, (B, F, 3, 2), nm)
+        need(aa_c, (B, F, 3), "aa_face_edges_normal_c")
     ana = _analytic(B, dev)
     if ana is None:
         need(ray_o, (B, ph, pw, 3), "image_ray_o"); need(ray_d, (B, ph, pw, 3), "image_ray_d")
@@ -242,6 +245,10 @@ def _make_desc(args, keep):
     d.flags = _flags
     for k, t in ts.items():
         setattr(d, k, t.data_ptr() if t.numel() > 0 else None)
+    if from_image:
+        d.flags |= DM2_FLAG_TABLES_FROM_IMAGE
+        for k in ("aa_face_verts", "aa_face_edges", "aa_face_edges_iszero", "aa_face_edges_recip", "aa_face_edges_normal", "aa_face_edges_normal_c"):
+            setattr(d, k, None)
     if ana is not None:
         cam, fw, fh = ana
         keep.append(cam)
@@ -308,6 +315,24 @@ class aa_grad_to_verts:
 
     def __exit__(self, *exc):
         _tls.aa_to_verts = self.old
+
+
+class tables_from_image:
+    """``with _C.tables_from_image(True): _C.render_forward_cuda(...)`` (and the matching backward): the six ``aa_*`` arguments
+    are placeholders (any tensors of the right rank, e.g. ``(B, 0, 3, 2)``) that are never read -- the plan builds the tables
+    per (view, face) from ``verts_image[faces]`` in registers, exactly as ``Triangles`` would (DM2_FLAG_TABLES_FROM_IMAGE).  For a
+    caller that owns the host prep (Renderer with the fused prep); the AA-corner gradients then come back per vertex
+    (``aa_grad_to_verts``).  A side channel like ``forward_only``: the 21 / 31-argument signatures stay the reference's."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = getattr(_tls, "tables_from_image", False)
+        _tls.tables_from_image = self.on
+
+    def __exit__(self, *exc):
+        _tls.tables_from_image = self.old
 
 
 class forward_mode:

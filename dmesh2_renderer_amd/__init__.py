@@ -30,6 +30,7 @@ __all__ = ["RenderFunction", "Renderer", "LayeredRenderer", "Triangles"]
 # selects the reference-shaped torch ops.
 _FUSED_PREP_DEFAULT = os.environ.get("DM2_FUSED_PREP", "1") != "0"
 _FUSED_AA_GRAD = os.environ.get("DM2_FUSED_AA_GRAD", "1") != "0"
+_TABLES_FROM_IMAGE = os.environ.get("DM2_TABLES_FROM_IMAGE", "1") != "0"     # fused prep: AA tables built inside the op's plan, never materialised
 _W_EPS = 1e-4   # |w| clamp of the projection, sign kept (reference __init__.py:254-255)
 
 
@@ -60,6 +61,7 @@ class RenderFunction(torch.autograd.Function):
         # fused host prep: the AA-corner gradients come back already scattered to the vertices' image coordinates
         # (input 9, verts_image) instead of as dL/d(aa_face_verts) (input 12) -- see _C.aa_grad_to_verts
         ctx.aa_to_verts = bool(getattr(_C._tls, "aa_to_verts", False))
+        ctx.tables_from_image = bool(getattr(_C._tls, "tables_from_image", False))
         try:
             with _C.forward_only(not any(ctx.needs_input_grad)):
                 out = _C.render_forward_cuda(*inputs)
@@ -90,7 +92,7 @@ class RenderFunction(torch.autograd.Function):
         try:
             ana = ctx.analytic
             with _C.analytic_rays(*(ana if ana is not None else (None, 0, 0))), _C.aa_grad_to_verts(ctx.aa_to_verts), \
-                    _C.forward_mode(ctx.fwd_mode):
+                    _C.forward_mode(ctx.fwd_mode), _C.tables_from_image(ctx.tables_from_image):
                 grads = _C.render_backward_cuda(
                     ctx.num_rendered, *inputs, grad_out_color, grad_out_depth,
                     face_buf, binning_buf, image_buf, oarea, tri_id, tri_cnt, doarea)
@@ -114,8 +116,12 @@ class Renderer(torch.nn.Module):
     precomputed for every camera at construction.
     """
 
-    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20, fused_prep=None, analytic_rays=False):
+    def __init__(self, mv, proj, width, height, device, aa_grad_buffer_size=20, fused_prep=None, analytic_rays=False,
+                 tables_from_image=None):
         super().__init__()
+        # not part of the reference's signature: with the fused prep, False hands the op the six materialised AA tables (the
+        # reference's 21 arguments as they are); the default lets the op build them from verts_image in its plan
+        self.tables_from_image = tables_from_image
         # not part of the reference's signature: analytic_rays=True keeps no (Bcam,H,W,3) ray tensors (49.8 MB per camera at
         # 1080p); the kernels compute each pixel's ray from inv(mv), inv(proj) in the operation order of _init_rays
         self.analytic_rays = bool(analytic_rays)
@@ -234,6 +240,21 @@ class Renderer(torch.nn.Module):
         f32 = torch.float32
         if getattr(self, "fused_prep", False) and verts.is_cuda:
             from . import prep
+            tfi = getattr(self, "tables_from_image", None)
+            if _FUSED_AA_GRAD and (_TABLES_FROM_IMAGE if tfi is None else tfi):
+                # the fused prep owns the AA tables end to end: they are never materialised -- the op's plan builds them per
+                # face from verts_image straight into its packed records (DM2_FLAG_TABLES_FROM_IMAGE; 114 B per face less to
+                # write and to read back), and the corner gradients come back per vertex, as the gradient of verts_image
+                verts_ndc, verts_image = prep.project(verts.to(f32), faces.to(torch.int32), mv.to(f32), proj.to(f32), self.width, self.height)
+                ph4 = torch.empty((B, 0, 3, 2), dtype=f32, device=verts.device)
+                with _C.tables_from_image(True), _C.aa_grad_to_verts(True):
+                    color, depth = RenderFunction.apply(
+                        background.to(f32), batch_patch_min.to(torch.int32), patch_width, patch_height,
+                        verts.to(f32), faces.to(torch.int32), verts_color.to(f32), faces_opacity.to(f32),
+                        verts_ndc, verts_image, faces_intense.to(f32), aa_temperature,
+                        ph4, ph4, ph4.to(torch.bool), ph4, ph4, torch.empty((B, 0, 3), dtype=f32, device=verts.device),
+                        self.aa_grad_buffer_size, ray_o.to(f32), ray_d.to(f32))
+                return color, 1.0 - (depth + 1.0) / 2.0
             (verts_ndc, verts_image, aa_v, aa_e, aa_z, aa_r, aa_n, aa_c) = prep.prepare(
                 verts.to(f32), faces.to(torch.int32), mv.to(f32), proj.to(f32), self.width, self.height)
             # the fused prep owns both ends of aa_face_verts: the op hands its corner gradients back per VERTEX (as the

@@ -108,6 +108,9 @@ int check_render_desc(const dm2_render_desc* d) {
     if (gx > 0xFFFF || gy > 0xFFFF) return fail("patch too large: more than 65535 tiles per axis");
     if (d->B > 65535) return fail("more than 65535 views per call");
     if ((int64_t)d->B * gx * gy >= (1ll << 31)) return fail("too many tiles");
+    if (!(d->flags & DM2_FLAG_TABLES_FROM_IMAGE) && d->B > 0 && d->F > 0 && d->P > 0 &&
+        (!d->aa_face_verts || !d->aa_face_edges || !d->aa_face_edges_iszero || !d->aa_face_edges_recip || !d->aa_face_edges_normal || !d->aa_face_edges_normal_c))
+        return fail("the aa_face_* tables must not be null (or set DM2_FLAG_TABLES_FROM_IMAGE)");
     if (d->flags & DM2_FLAG_ANALYTIC_RAYS) {
         if (!d->ray_cam && d->B > 0) return fail("DM2_FLAG_ANALYTIC_RAYS needs ray_cam");
         if (d->full_W <= 0 || d->full_H <= 0) return fail("DM2_FLAG_ANALYTIC_RAYS needs the full image size");

@@ -236,6 +236,13 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
                             hipStream_t st) {
     const uint64_t* const hit_masks = bs.hit_masks; const uint32_t* const hit_valid = bs.hit_valid;
     const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    const bool fast_only = !(d.flags & DM2_FLAG_LEGACY_KERNELS) && d.aa_temperature > 0.0f && hit_masks && hit_valid && fwd_mode == DM2_FWD_POOL &&
+                           bs.pool && bs.pool_cap > 0 && tie_queue && tie_cap > 0;
+    if (fast_only) {      // (times its two kernels as two stages)
+        launch_render_backward_fast(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color, dL_dfaces_opacity,
+                                    dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs, tie_queue, tie_cap, false, st);
+        return;
+    }
     StageTimer tm(ST_BWD, st);
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         // aa_temperature == 0: no bbox test in the reference (backward.cu:241-244), every face of a tile's list meets

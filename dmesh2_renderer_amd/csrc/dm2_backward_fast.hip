@@ -521,33 +521,57 @@ k_aa_ties(dm2_render_desc d, const uint4* __restrict__ face_recs, const TieEntry
     if (check_mode && counters[0] != 3u) return;
     const uint32_t n = min(counters[2], cap);
     const bool to_verts = (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) != 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const TieEntry e = queue[i];
+    // (wave-uniform trip count: the lanes of a wave reduce over runs of equal faces with DPP before the atomics -- a face's ties
+    // come from neighbouring lanes of one wave of the main kernel and sit next to each other in the queue)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < n;
+        TieEntry e = tie_pack(0u, 0u, 0u, 0u, 0.0f);
+        if (valid) e = queue[i];
         uint32_t b, x, y;
         tie_unpack(e, b, x, y);
         const int64_t bf = (int64_t)b * d.F + e.face;
         const uint4* src = face_recs + bf * FACE_REC_U4;
         AAFace f;
-        uint4* dst = reinterpret_cast<uint4*>(&f);
+        float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            uint4* dst = reinterpret_cast<uint4*>(&f);
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = src[k];                              // the AA tables: the record's first 128 bytes
-        const float pxmin = (float)(x + (uint32_t)d.patch_min[2 * b]), pymin = (float)(y + (uint32_t)d.patch_min[2 * b + 1]);
-        float area, g[6];
-        seg_area_grad(f, pxmin, pxmin + 1, pymin, pymin + 1, 1.0f, area, g, false);
+            for (int k = 0; k < 8; k++) dst[k] = src[k];                          // the AA tables: the record's first 128 bytes
+            const float pxmin = (float)(x + (uint32_t)d.patch_min[2 * b]), pymin = (float)(y + (uint32_t)d.patch_min[2 * b + 1]);
+            float area;
+            seg_area_grad(f, pxmin, pxmin + 1, pymin, pymin + 1, 1.0f, area, g, false);
+#pragma unroll
+            for (int c = 0; c < 6; c++) g[c] *= e.dL_doarea;
+        }
+        // runs of equal (view, face) inside 16-lane rows
+        // (runs by CONTIGUITY: the same face may come back further down the queue -- another tile's batch -- with other faces in
+        // between; lane l - K is in lane l's run only if every lane between them is)
+        const int key = valid ? (int)e.face : -1 - (int)lane, kv = (int)b, l16 = (int)(lane & 15u);
+        const int cont = ((l16 >= 1) & (dpp_shr_i<1>(key) == key) & (dpp_shr_i<1>(kv) == kv)) ? 1 : 0;     // continues the lane before
+        const int c2 = cont & dpp_shr_i<1>(cont), c4 = c2 & dpp_shr_i<2>(c2), c8 = c4 & dpp_shr_i<4>(c4);
+        const bool s1 = cont != 0, s2 = (c2 != 0) & (l16 >= 2), s4 = (c4 != 0) & (l16 >= 4), s8 = (c8 != 0) & (l16 >= 8);
+        const bool last = (l16 == 15) | (dpp_shl_i<1>(cont) == 0);
+#pragma unroll
+        for (int c = 0; c < 6; c++) seg_scan16(g[c], s1, s2, s4, s8);
+        const bool emit = valid & last;
+        if (!emit) continue;
         if (to_verts) {
             const uint4 ids = src[14];                                            // vid[0..2] are dwords 56..58 of the record
             const int vid[3] = {(int)ids.x, (int)ids.y, (int)ids.z};
-            const bool flip = (f.zmask >> 8) & 1u;
+            const uint32_t zm = src[4].z;                                         // zmask: dword 18
+            const bool flip = (zm >> 8) & 1u;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const int v = vid[c == 0 ? 0 : (flip ? 3 - c : c)];
                 float* dstp = dL_daa_face_verts + ((int64_t)b * d.P + v) * 2;
-                atomicAdd(dstp, e.dL_doarea * g[2 * c]); atomicAdd(dstp + 1, e.dL_doarea * g[2 * c + 1]);
+                atomicAdd(dstp, g[2 * c]); atomicAdd(dstp + 1, g[2 * c + 1]);
             }
         } else {
             float* dstp = dL_daa_face_verts + bf * 6;
 #pragma unroll
-            for (int c = 0; c < 6; c++) atomicAdd(dstp + c, e.dL_doarea * g[c]);
+            for (int c = 0; c < 6; c++) atomicAdd(dstp + c, g[c]);
         }
     }
     __shared__ uint32_t s_ticket;
@@ -565,10 +589,14 @@ void launch_render_backward_fast(const dm2_render_desc& d, const uint2* ranges, 
                                  bool check_mode, hipStream_t st) {
     const uint32_t Tn = (uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B);
     const uint32_t cap = (uint32_t)(tie_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : tie_cap);
-    hipLaunchKernelGGL(k_render_backward_fast, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
-                       dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
-                       bs.hit_masks, bs.hit_valid, bs.hit_base, bs.pool, tie_queue, cap, check_mode STAMP_ARG(1));
+    {
+        StageTimer tm(check_mode ? -1 : ST_BWD, st);       // (under DM2_FWD_UNKNOWN the caller times the whole cascade)
+        hipLaunchKernelGGL(k_render_backward_fast, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+                           dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
+                           bs.hit_masks, bs.hit_valid, bs.hit_base, bs.pool, tie_queue, cap, check_mode STAMP_ARG(1));
+    }
     const unsigned blocks = (unsigned)((cap + 255u) / 256u < 1024u ? (cap + 255u) / 256u : 1024u);
+    StageTimer tm(check_mode ? -1 : ST_TIES, st);
     if (blocks) hipLaunchKernelGGL(k_aa_ties, dim3(blocks), dim3(256), 0, st, d, is.face_recs, tie_queue, cap, bs.hit_valid, dL_daa_face_verts, check_mode);
 }
 

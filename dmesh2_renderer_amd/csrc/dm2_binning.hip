@@ -224,8 +224,9 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
+    __shared__ unsigned long long s_pairs;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) s_max = 0;
+    if (tid == 0) { s_max = 0; s_pairs = 0ull; }
     uint32_t carry = 0, mx = 0;
     unsigned long long carry64 = 0;                       // the list positions are 32-bit (as the reference's int num_rendered): notice a wrap
     for (int64_t base = 0; base < Tn; base += ROUND) {
@@ -261,11 +262,17 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
         __syncthreads();                                   // s_c and s_w are rewritten by the next round
     }
     if (mx) atomicMax(&s_max, mx);
+    {   // the pair bound: one partial sum per thread (PAIR_PARTS == blockDim.x), summed over the block
+        static_assert(PAIR_PARTS == 1024, "one partial sum per thread of k_tile_scan");
+        unsigned long long v = pair_part[tid];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && v) atomicAdd(&s_pairs, v);
+    }
     __syncthreads();
     if (tid == 0) {
         const uint32_t longest = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max;      // (per-round totals stay below 2^32: 8192 tiles)
-        unsigned long long pairs = 0;
-        for (int k = 0; k < PAIR_PARTS; k++) pairs += pair_part[k];
+        const unsigned long long pairs = s_pairs;
         meta[0] = carry; meta[1] = longest; meta[2] = (uint32_t)pairs; meta[3] = (uint32_t)(pairs >> 32);
         if (host_meta) {
             // the numbers the host waits for, straight into its mapped memory, then the sequence word it polls: no copy

@@ -233,7 +233,11 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // pair pool: the chunk takes one slot per survivor (>= the pairs that blend) -- one atomic per chunk, issued here and
         // looked at behind B2
         uint32_t cbase = 0;
+#if defined(DM2_FQ_POOL_EXP) && DM2_FQ_POOL_EXP == 1     // timing experiment only: no allocation
+        if (pool && tid == 0) cbase = (tile * 4096u + (uint32_t)base * 16u) % (pool_cap - 600u);
+#else
         if (pool && tid == 0) cbase = atomicAdd(hit_valid + 1, (uint32_t)S);
+#endif
         // ---- phase B2: one survivor per lane ------------------------------------------------
         // (at most two rounds of 256 survivors: SURVCAP.  Pool: a blending survivor's slot is the chunk's first slot + its rank
         // among the chunk's blending survivors -- survivor order is (entry, pixel) order, the order of the masks -- taken with a
@@ -325,8 +329,10 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const uint4 c03 = reinterpret_cast<const uint4*>(s_rcnt)[0], c47 = reinterpret_cast<const uint4*>(s_rcnt)[1];
             const uint32_t r0 = (wid > 0 ? c03.x : 0u) + (wid > 1 ? c03.y : 0u) + (wid > 2 ? c03.z : 0u);
             const uint32_t r1 = c03.x + c03.y + c03.z + c03.w + (wid > 0 ? c47.x : 0u) + (wid > 1 ? c47.y : 0u) + (wid > 2 ? c47.z : 0u);
+#if !defined(DM2_FQ_POOL_EXP) || DM2_FQ_POOL_EXP != 2     // (2: timing experiment only, no pool stores)
             if (pool_rank[0] >= 0) { const uint32_t slot = cb + r0 + (uint32_t)pool_rank[0]; if (slot < pool_cap) pool[slot] = pool_ratio[0]; }
             if (pool_rank[1] >= 0) { const uint32_t slot = cb + r1 + (uint32_t)pool_rank[1]; if (slot < pool_cap) pool[slot] = pool_ratio[1]; }
+#endif
         }
 
         // ---- phase C: ordered blend of this pixel's records ---------------------------------

@@ -114,13 +114,37 @@ __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int f
     r.opacity = d.faces_opacity[face_id];
     const int64_t bf = (int64_t)b * d.F + face_id;
     r.intense = d.faces_intense[bf];
+    uint32_t zm = 0;
+    if (d.flags & DM2_FLAG_TABLES_FROM_IMAGE) {
+        // The six AA tables are pure functions of the face's three image-space corners (pyrenderer.py:6-30, 521-535): built
+        // here in registers, in the operation order of the fused host prep (dm2_prep.hip k_aa_tables: bit-identical tables),
+        // instead of being written by the host prep (114 B per face) and read back here.
+        const float2* im = reinterpret_cast<const float2*>(d.verts_image) + (int64_t)b * d.P;
+        const float2 p0 = im[v0], p1 = im[v1], p2 = im[v2];
+        const float area2 = 0.5f * ((p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y));
+        const bool flip = area2 < 0.0f;                               // clockwise: corners 1 and 2 swap (pyrenderer.py:521-535)
+        const float2 q[3] = {p0, flip ? p2 : p1, flip ? p1 : p2};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float2 sv = q[i], ev = q[(i + 1) % 3];
+            const float ex = ev.x - sv.x, ey = ev.y - sv.y;
+            const float nx = -ey, ny = ex;
+            r.aa.v[2 * i] = sv.x; r.aa.v[2 * i + 1] = sv.y;
+            r.aa.e[2 * i] = ex; r.aa.e[2 * i + 1] = ey;
+            r.aa.r[2 * i] = 1.0f / ex; r.aa.r[2 * i + 1] = 1.0f / ey;
+            r.aa.n[2 * i] = nx; r.aa.n[2 * i + 1] = ny;
+            r.aa.c[i] = nx * sv.x + ny * sv.y;
+            zm |= (fabsf(ex) < 1e-3f ? 1u : 0u) << (2 * i);
+            zm |= (fabsf(ey) < 1e-3f ? 1u : 0u) << (2 * i + 1);
+        }
+        if (flip) zm |= 1u << 8;                                      // (DM2_FLAG_AA_GRAD_TO_VERTS routes the corner gradients back with it)
+    } else {
     const float2* av = reinterpret_cast<const float2*>(d.aa_face_verts + bf * 6);
     const float2* ae = reinterpret_cast<const float2*>(d.aa_face_edges + bf * 6);
     const float2* ar = reinterpret_cast<const float2*>(d.aa_face_edges_recip + bf * 6);
     const float2* an = reinterpret_cast<const float2*>(d.aa_face_edges_normal + bf * 6);
     const float* ac = d.aa_face_edges_normal_c + bf * 3;
     const uint8_t* az = d.aa_face_edges_iszero + bf * 6;
-    uint32_t zm = 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float2 a = av[i], e = ae[i], rr = ar[i], n = an[i];
@@ -137,6 +161,7 @@ __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int f
     if (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) {                    // (only a forward that announces such a backward pays the gather)
         const float2 iv1 = *reinterpret_cast<const float2*>(d.verts_image + ((int64_t)b * d.P + v1) * 2);
         if (!(av[1].x == iv1.x && av[1].y == iv1.y)) zm |= 1u << 8;
+    }
     }
     r.aa.zmask = zm;
     // aa_face_verts.min(2)/.max(2)  (forward.cu:480-481, backward.cu:589-590)

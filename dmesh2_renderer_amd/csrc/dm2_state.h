@@ -34,7 +34,8 @@ struct Carver {
 // of indices), and again by the backward: the gradients belong to the inputs the forward saw.
 constexpr int FACE_REC_U4 = 16;            // uint4 per record (256 B)
 
-constexpr int PAIR_PARTS = 64;             // the plan's pair-bound sum is kept in this many partial sums (one atomic per wave, spread)
+constexpr int PAIR_PARTS = 1024;           // the plan's pair-bound sum is kept in this many partial sums (one atomic per wave, spread: atomics on one
+                                            // address are serialised by the L2; 16 k of them on 64 addresses cost the plan 0.02 ms)
 
 // per (batch,face): produced by the preprocess kernel
 struct FaceState {
@@ -208,12 +209,12 @@ void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* r
 
 // ---- optional per-stage hipEvent timing (dm2_profile_enable; defined in dm2_api.hip) ----
 namespace dm2 {
-enum Stage { ST_PREP = 0, ST_EMIT = 1, ST_SORT = 2, ST_RANGES = 3, ST_FWD = 4, ST_BWD = 5 };
+enum Stage { ST_PREP = 0, ST_EMIT = 1, ST_SORT = 2, ST_RANGES = 3, ST_FWD = 4, ST_BWD = 5, ST_TIES = 6 };
 void prof_begin(int stage, hipStream_t st);
 void prof_end(int stage, hipStream_t st);
 struct StageTimer {
     int s; hipStream_t st;
-    StageTimer(int stage, hipStream_t stream) : s(stage), st(stream) { prof_begin(s, st); }
-    ~StageTimer() { prof_end(s, st); }
+    StageTimer(int stage, hipStream_t stream) : s(stage), st(stream) { if (s >= 0) prof_begin(s, st); }     // stage < 0: times nothing
+    ~StageTimer() { if (s >= 0) prof_end(s, st); }
 };
 }  // namespace dm2

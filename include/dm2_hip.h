@@ -93,6 +93,13 @@ typedef struct dm2_render_desc {
                                     that owns the host prep as well (dmesh2_renderer_amd/prep.py).  The flag must be set in the
                                     forward call of the same frame too: that is when the record notes the reorder. */
 
+#define DM2_FLAG_TABLES_FROM_IMAGE 32 /* dm2_forward*: the six aa_* tables are not read (their pointers may be NULL): the plan builds them
+                                    per (view, face) from verts_image[faces] in registers -- CCW reorder, edges, |e| < 1e-3 flags,
+                                    reciprocals, inward normals and their offsets, exactly as pyrenderer.py:6-30 / dm2_prepare_faces
+                                    compute them -- straight into its packed face records.  For a caller that owns the host prep
+                                    (SURVEY.md 8(f) rank 1): 114 B per face less to write and 114 to read.  The backward's dL/d(aa
+                                    corners) then only exists per vertex: combine with DM2_FLAG_AA_GRAD_TO_VERTS. */
+
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 2 * (B*tiles) + 1 for Renderer (holds the packed face records,
@@ -279,8 +286,9 @@ int dm2_debug_aa_overlap(int variant, int64_t n, const float* aa_face_verts, con
  * milliseconds of each stage of the most recent forward_plan/forward_run/backward call:
  * [0] preprocess + tile scan  [1] scatter into the tile segments (radix route: scan + key emit)
  * [2] per-tile sorts (radix route: the radix sort)  [3] tile ranges (radix route only)
- * [4] forward composite [5] backward composite.  Returns the number of values written. */
-#define DM2_PROFILE_STAGES 6
+ * [4] forward composite [5] backward composite [6] the backward's tie pass (k_aa_ties; 0 when another backward kernel
+ * ran).  Returns the number of values written. */
+#define DM2_PROFILE_STAGES 7
 void dm2_profile_enable(int on);
 int dm2_profile_read(float* ms, int capacity);
 

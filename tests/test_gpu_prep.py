@@ -202,6 +202,49 @@ def test_fused_aa_gradient_routing(legacy):
         assert rel(b, a) <= 1e-5
 
 
+@pytest.mark.parametrize("legacy,temp", [(False, 1.0), (True, 1.0), (False, 0.0)])
+def test_tables_from_image_matches_materialised_tables(legacy, temp):
+    """The fused prep's default never materialises the six AA tables: the op's plan builds them per (view, face) from
+    verts_image straight into its packed records (DM2_FLAG_TABLES_FROM_IMAGE).  Same bits in the image, same leaf gradients
+    as with the tables written by dm2_prepare_faces and read back -- both orientations, shared vertices, two views, patches."""
+    import dmesh2_renderer_amd as dm2
+    from dmesh2_renderer_amd import _C
+    W, H, F = 112, 72, 900
+    sc = mixed_orientation(scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 48, num_cams=2, shared_verts=True)).to("cuda")
+    pm = torch.tensor([[8, 4], [0, 0]], dtype=torch.int64, device="cuda")
+    pw, ph = 96, 64
+    gen = torch.Generator().manual_seed(12)
+    gc, gd = torch.randn((2, ph, pw, 3), generator=gen).cuda(), torch.randn((2, ph, pw), generator=gen).cuda()
+    res, seen = [], []
+    old_flags = _C.set_flags(_C.DM2_FLAG_LEGACY_KERNELS if legacy else 0)
+    old_mode = dm2._TABLES_FROM_IMAGE
+    real = _C.render_forward_cuda
+
+    def spy(*args):
+        seen.append(tuple(args[12].shape))
+        return real(*args)
+
+    _C.render_forward_cuda = spy
+    try:
+        for from_image in (False, True):
+            dm2._TABLES_FROM_IMAGE = from_image
+            r = dm2.Renderer(sc.mv, sc.proj, W, H, "cuda", fused_prep=True)
+            leaves = [t.clone().requires_grad_(True) for t in (sc.verts, sc.verts_color, sc.faces_opacity, sc.faces_intense)]
+            color, depth = r([1, 0], pm, pw, ph, leaves[0], sc.faces, leaves[1], leaves[2], leaves[3], sc.background, aa_temperature=temp)
+            torch.autograd.backward([color, depth], [gc, gd])
+            res.append((color.detach().cpu().numpy(), depth.detach().cpu().numpy(), [t.grad.cpu().numpy() for t in leaves]))
+    finally:
+        dm2._TABLES_FROM_IMAGE = old_mode
+        _C.set_flags(old_flags)
+        _C.render_forward_cuda = real
+    assert seen == [(2, F, 3, 2), (2, 0, 3, 2)]                 # tables handed over, then placeholders
+    (c0, d0, g0), (c1, d1, g1) = res
+    assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
+    assert np.abs(g0[0]).max() > 0
+    for a, b in zip(g0, g1):
+        assert rel(b, a) <= 1e-5
+
+
 def test_layered_renderer_fused_projection():
     import dmesh2_renderer_amd as dm2
     sc = scenes.tet_lattice(64, 64, 4, scenes.SEED_BASE + 46).to("cuda")

@@ -44,7 +44,7 @@ def capture_forward_args(sc, batch_idx, patch_min, pw, ph, temp=1.0, K=20, devic
         return (0, z((B, ph, pw, 3), device=device), z((B, ph, pw), device=device), z(0), z(0), z(0), z(0), z(0), z(0), z(0))
 
     scd = sc.to(device)
-    r = dm2.Renderer(scd.mv, scd.proj, sc.width, sc.height, device, aa_grad_buffer_size=K)
+    r = dm2.Renderer(scd.mv, scd.proj, sc.width, sc.height, device, aa_grad_buffer_size=K, tables_from_image=False)   # (the arguments are replayed as they are)
     with patched_C(render_forward_cuda=fake):
         r(batch_idx, torch.tensor(patch_min, dtype=torch.int64, device=device), pw, ph, scd.verts, scd.faces,
           scd.verts_color, scd.faces_opacity, scd.faces_intense[batch_idx], scd.background, aa_temperature=temp)

@@ -18,8 +18,8 @@ import bench  # noqa: E402
 FWDQ = ["prologue", "top barrier", "stage faces", "scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
         "barrier + phase C (blend)", "epilogue"]
 BWDM = ["prologue", "top of chunk", "-", "scan + cut + decode (every wave for itself)", "-",
-        "phase B2 (clip+grad, shade)", "barrier after B2 + request of the next chunk", "phase C (replay)", "barrier after C",
-        "phase D (chain + dpp + lds atomics)", "barrier after D", "flush atomics"]
+        "phase B2 (pool ratio, intersection, shade)", "barrier after B2 + request of the next chunk", "phase C (replay)", "barrier after C",
+        "phase D (chain + AA Jacobian + dpp + lds atomics)", "barrier after D", "flush atomics"]
 BWDQ = ["prologue", "top barrier", "stage faces", "zero+scan+barrier+cut", "phase B1 (classify+compact)+barrier", "phase B2 (survivors)",
         "barrier + phase C (replay)", "-", "barrier after C", "phase D (chain+dpp+lds atomics)", "barriers before flush", "flush atomics"]
 

@@ -41,7 +41,14 @@ CONFIGS = {
     "cfg2": (512, 512, 50_000, 2),
     "cfg1": (256, 256, 2_000, 1),
     "cfg5": (3840, 2160, 2_000_000, 5),     # BASELINE configs[4] (quoted on 8 GPUs; fits one MI355X: ~1.3 GB of tensors)
+    # the reference's own parallel axis is the batch of views (forward.cu:191 blockIdx.z, renderer.cu:457): four cameras on the
+    # cfg4 scene, each rendering one 512 x 512 window of its 1080p image in ONE call (B = 4)
+    "cfg4_b4": (1920, 1080, 1_000_000, 4),
+    # large triangles, depth complexity 60 (SURVEY 8(d) generator with 15 x the coverage): most pairs are fully covered
+    "cfg1_dc60": (256, 256, 2_000 * 15, 1),
 }
+VIEWS = {"cfg4_b4": dict(cams=4, pw=512, ph=512, pm=[[0, 0], [704, 284], [1408, 568], [640, 0]])}
+DEPTH_COMPLEXITY = {"cfg1_dc60": 60.0}
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6.29e12
 
 
@@ -67,7 +74,12 @@ def build_inputs(cfg, device, rank, world):
     import dmesh2_renderer_amd as dm2
     from dmesh2_renderer_amd import _C
     W, H, F, ci = CONFIGS[cfg]
-    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci).to(device)
+    view = VIEWS.get(cfg)
+    kw = dict(num_cams=view["cams"]) if view else {}
+    if cfg in DEPTH_COMPLEXITY:
+        # (the generator sizes the triangles for a mean depth complexity of 4 at F faces: same triangles, 15 x as many)
+        kw["depth_complexity"] = DEPTH_COMPLEXITY[cfg]
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci, **kw).to(device)
     _LAST["scene"] = sc
     got = {}
     real = _C.render_forward_cuda
@@ -83,15 +95,21 @@ def build_inputs(cfg, device, rank, world):
     _C.render_forward_cuda = capture
     try:
         with torch.no_grad():
-            r([0], torch.zeros((1, 2), dtype=torch.int64, device=device), W, H, sc.verts, sc.faces, sc.verts_color,
-              sc.faces_opacity, sc.faces_intense, sc.background, aa_temperature=AA_TEMPERATURE)
+            if view:
+                bidx = list(range(view["cams"]))
+                r(bidx, torch.tensor(view["pm"], dtype=torch.int64, device=device), view["pw"], view["ph"], sc.verts, sc.faces, sc.verts_color,
+                  sc.faces_opacity, sc.faces_intense[bidx], sc.background, aa_temperature=AA_TEMPERATURE)
+            else:
+                r([0], torch.zeros((1, 2), dtype=torch.int64, device=device), W, H, sc.verts, sc.faces, sc.verts_color,
+                  sc.faces_opacity, sc.faces_intense, sc.background, aa_temperature=AA_TEMPERATURE)
     finally:
         _C.render_forward_cuda = real
     args = list(got["args"])
     g = torch.Generator().manual_seed(scenes.SEED_BASE + 100 + ci)
-    dLc = torch.randn((1, H, W, 3), generator=g).to(device)
-    dLd = torch.randn((1, H, W), generator=g).to(device)
-    return args, dLc, dLd, (W, H, F)
+    Bv, ph, pw = (view["cams"], view["ph"], view["pw"]) if view else (1, H, W)
+    dLc = torch.randn((Bv, ph, pw, 3), generator=g).to(device)
+    dLd = torch.randn((Bv, ph, pw), generator=g).to(device)
+    return args, dLc, dLd, (pw, ph, F)
 
 
 def host_prep_ms(cfg, device, iters=10):
@@ -303,6 +321,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1088,
                     help="rows of the frame the CPU baseline renders (default: the whole 1080p frame, a few seconds on a 128-thread host)")
     opt = ap.parse_args()
+    if opt.config in VIEWS or opt.config in DEPTH_COMPLEXITY:
+        opt.no_cpu = True              # (the side legs -- host prep, end to end, CPU baseline -- belong to the BASELINE configs)
     global AA_TEMPERATURE
     AA_TEMPERATURE = opt.aa_temperature
 
@@ -488,7 +508,7 @@ def main():
         tri_cnt = op.fwd[5] if op.fwd is not None else None
         bwd_ms = max(stage_ms.get("backward_composite", 0.0), 1e-9)
         cfg = {
-            "workload": f"Renderer forward+backward {W}x{H}, {F} triangles (soup, P=3F), B=1, aa_temperature={AA_TEMPERATURE}, K=20, "
+            "workload": f"Renderer forward+backward {W}x{H}{' windows of 1920x1080 cameras' if opt.config in VIEWS else ''}, {F} triangles (soup, P=3F), B={B}, aa_temperature={AA_TEMPERATURE}, K=20, "
                         f"AA visibility gradients on ({'BASELINE configs[3]' if opt.config == 'cfg4' else opt.config})",
             "sharding": "single GPU" if world == 1 else f"tile-row bands x{world}, exchange={reduce_mode}",
             "num_rendered_rank0": int(R), "grad_Mtris_per_s": round(F / bwd_ms / 1e3, 2),
@@ -504,7 +524,7 @@ def main():
             cfg["grad_Mtris_per_s"] = round(F / (ms_step * 1e-3) / 1e6, 2)     # whole job: every face's gradient per step
         out = {
             "metric": "Mpixels/s fwd+bwd @1080p/1M tris" if (opt.config == "cfg4" and AA_TEMPERATURE == 1.0) else f"Mpixels/s fwd+bwd ({opt.config})",
-            "value": round(W * H / (ms_step * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+            "value": round(B * W * H / (ms_step * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfg, "roofline": roofline,

@@ -34,7 +34,7 @@ DM2_FLAG_AA_GRAD_TO_VERTS = 16
 DM2_FLAG_TABLES_FROM_IMAGE = 32
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS, SCRATCH_PAIR_POOL, SCRATCH_TIE_QUEUE = range(7)
 # what a forward left for its backward (include/dm2_hip.h DM2_FWD_*)
-FWD_UNKNOWN, FWD_NONE, FWD_MASKS, FWD_POOL = 0, 1, 2, 3
+FWD_UNKNOWN, FWD_NONE, FWD_MASKS, FWD_POOL, FWD_POINT = 0, 1, 2, 3, 4
 ABI_VERSION = 6
 
 # opt-in flags applied to every call (tests use this for the corrected-gradient mode)
@@ -91,6 +91,9 @@ EXPORTS = {
     "dm2_layers_run": (ctypes.c_int, [ctypes.POINTER(LayersDesc), _i64, _i64, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "dm2_prepare_faces": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp]),
     "dm2_prepare_faces_backward": (ctypes.c_int, [ctypes.POINTER(PrepDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dm2_exchange_mark": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "dm2_exchange_pack": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dm2_exchange_unpack": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dm2_debug_aa_overlap": (ctypes.c_int, [ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dm2_debug_fetch": (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64, _vp, _sz, _vp, _vp]),
     "dm2_profile_enable": (None, [ctypes.c_int]),
@@ -662,3 +665,48 @@ def touched_faces(face_buf, B, F):
     (tiles_touched of the face scratch; dm2_debug_fetch item 8).  The sharded exchange sends only those rows."""
     t = debug_fetch(8, B * F, 1, 0, face_buf, torch.int32, B * F)
     return (t.view(B, F) != 0).any(dim=0)
+
+
+# ---- device side of the sharded step's sparse exchange (include/dm2_hip.h: dm2_exchange_*) --------------------------------
+def exchange_mark(face_buf, faces, B, P, N):
+    """-> (flags (F + P) uint8: face flags then vertex flags, counts (N, 2) int32: rows this rank will send to every owner)."""
+    lib = load_library()
+    dev = _require_gpu(face_buf, faces)
+    F = faces.shape[0]
+    fc = _c(faces, torch.int32)
+    flags = torch.empty((F + P,), dtype=torch.uint8, device=dev)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        if lib.dm2_exchange_mark(B, P, F, N, _ptr(fc), _ptr(face_buf), face_buf.numel(), _ptr(flags), _ptr(counts), _stream(dev)):
+            raise _err(lib, "dm2_exchange_mark")
+    return flags, counts
+
+
+def exchange_pack(flags, counts, total_floats, dverts, dcolor, dopacity, dintense):
+    """-> the send buffer (total_floats float32): per owner [face rows | vertex rows] (see dm2_exchange_pack)."""
+    lib = load_library()
+    dev = _require_gpu(flags, counts, dverts, dcolor, dopacity, dintense)
+    f32 = torch.float32
+    P, F, B, N = dverts.shape[0], dopacity.shape[0], dintense.shape[0], counts.shape[0]
+    ts = [_c(dverts, f32), _c(dcolor, f32), _c(dopacity, f32), _c(dintense, f32)]
+    send = torch.empty((int(total_floats),), dtype=f32, device=dev)
+    cursors = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        if lib.dm2_exchange_pack(B, P, F, N, _ptr(flags), _ptr(counts), _ptr(cursors), *[_ptr(t) for t in ts], _ptr(send), _stream(dev)):
+            raise _err(lib, "dm2_exchange_pack")
+    return send
+
+
+def exchange_unpack(recv, recv_counts, rows, rank, B, P, F):
+    """-> (slice_v (ceil(P/N), 6), slice_f (ceil(F/N), 1 + B)): the owner's sums of the received rows."""
+    lib = load_library()
+    dev = _require_gpu(recv, recv_counts)
+    N = recv_counts.shape[0]
+    Ps, Fs = -(-P // N), -(-F // N)
+    slice_v = torch.empty((Ps, 6), dtype=torch.float32, device=dev)
+    slice_f = torch.empty((Fs, 1 + B), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if lib.dm2_exchange_unpack(B, P, F, N, int(rank), _ptr(recv), _ptr(_c(recv_counts, torch.int32)), int(rows), _ptr(slice_v), _ptr(slice_f),
+                                   _stream(dev)):
+            raise _err(lib, "dm2_exchange_unpack")
+    return slice_v, slice_f

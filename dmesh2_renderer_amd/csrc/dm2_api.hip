@@ -296,7 +296,7 @@ int dm2_backward(const dm2_render_desc* d, int64_t num_rendered, int32_t forward
     if (dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) > image_bytes) return fail("image scratch too small");
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, num_rendered, Tn) > binning_bytes) return fail("binning scratch too small");
     dm2::ImageState is = dm2::ImageState::carve(const_cast<void*>(image_scratch), N, Tn);
-    if (forward_mode < DM2_FWD_UNKNOWN || forward_mode > DM2_FWD_POOL) return fail("forward_mode must be one of DM2_FWD_*");
+    if (forward_mode < DM2_FWD_UNKNOWN || forward_mode > DM2_FWD_POINT) return fail("forward_mode must be one of DM2_FWD_*");
     dm2::BinningState bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn), nullptr, binning_bytes);
     is.face_recs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, Tn, dm2::scan_temp_bytes(BF), true).recs;
     // the tie queue holds at most one entry per pair of the pool
@@ -399,6 +399,50 @@ int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc,
     if (d->P > 0 && !g_verts) return fail("g_verts must not be null");
     if (g_aa_face_verts && d->F > 0 && d->B > 0 && d->P > 0 && !image_grad_scratch) return fail("image_grad_scratch must not be null");
     dm2::launch_prepare_faces_backward(*d, g_verts_ndc, g_verts_image, g_aa_face_verts, image_grad_scratch, g_verts, (hipStream_t)stream);
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_exchange(int32_t B, int32_t P, int32_t F, int32_t N) {
+    if (B < 0 || P < 0 || F < 0) return fail("negative size");
+    if (N < 1 || N > dm2::exchange_max_ranks()) return fail("dm2_exchange_*: 1 <= N <= 64 ranks");
+    return 0;
+}
+
+int dm2_exchange_mark(int32_t B, int32_t P, int32_t F, int32_t N, const int32_t* faces, const void* face_scratch, size_t face_bytes,
+                      uint8_t* flags, uint32_t* counts, void* stream) {
+    if (check_exchange(B, P, F, N)) return 1;
+    if (!flags || !counts) return fail("dm2_exchange_mark: null output");
+    const int64_t BF = (int64_t)B * F;
+    const uint32_t* touched = nullptr;
+    if (BF > 0 && P > 0) {
+        if (!faces || !face_scratch) return fail("dm2_exchange_mark: null input");
+        dm2::FaceState fs = dm2::FaceState::carve(const_cast<void*>(face_scratch), BF, 0, dm2::scan_temp_bytes(BF), false);
+        touched = fs.tiles_touched;
+        if ((size_t)((const char*)(touched + BF) - (const char*)face_scratch) > face_bytes) return fail("dm2_exchange_mark: face scratch too small");
+    }
+    DM2_HIP(dm2::launch_exchange_mark(B, P, F, N, faces, touched, flags, counts, (hipStream_t)stream));
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+int dm2_exchange_pack(int32_t B, int32_t P, int32_t F, int32_t N, const uint8_t* flags, const uint32_t* counts, uint32_t* cursors,
+                      const float* dverts, const float* dverts_color, const float* dfaces_opacity, const float* dfaces_intense,
+                      float* send, void* stream) {
+    if (check_exchange(B, P, F, N)) return 1;
+    if (!flags || !counts || !cursors) return fail("dm2_exchange_pack: null scratch");
+    if (P > 0 && F > 0 && (!dverts || !dverts_color || !dfaces_opacity || !dfaces_intense)) return fail("dm2_exchange_pack: null gradient");
+    DM2_HIP(dm2::launch_exchange_pack(B, P, F, N, flags, counts, cursors, dverts, dverts_color, dfaces_opacity, dfaces_intense, send, (hipStream_t)stream));
+    DM2_HIP(hipGetLastError());
+    return 0;
+}
+
+int dm2_exchange_unpack(int32_t B, int32_t P, int32_t F, int32_t N, int32_t rank, const float* recv, const uint32_t* recv_counts,
+                        int64_t rows, float* slice_v, float* slice_f, void* stream) {
+    if (check_exchange(B, P, F, N)) return 1;
+    if (rank < 0 || rank >= N) return fail("dm2_exchange_unpack: rank out of range");
+    if (!slice_v || !slice_f || !recv_counts || (rows > 0 && !recv)) return fail("dm2_exchange_unpack: null pointer");
+    DM2_HIP(dm2::launch_exchange_unpack(B, P, F, N, rank, recv, recv_counts, rows, slice_v, slice_f, (hipStream_t)stream));
     DM2_HIP(hipGetLastError());
     return 0;
 }

@@ -251,6 +251,14 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
         // reference-shaped per-pixel walk below instead (A/B).
 #ifndef DM2_POINT_PER_PIXEL
         if (!(d.aa_temperature > 0.0f)) {
+            if (fwd_mode == DM2_FWD_POINT && hit_masks && hit_valid) {
+                // the masks of this frame's dm2_forward_point.hip drive the same kernel as at temperature > 0 (coverage 1, no AA terms)
+                launch_render_backward_fast(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color, dL_dfaces_opacity,
+                                            dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts, bs, nullptr, 0, false, st);
+                return;
+            }
+            // (what the forward left is not known, or it left nothing: dm2_backward_point.hip looks at hit_valid itself and
+            // repeats the dense intersection test when the masks are not this frame's)
             launch_render_backward_point(d, ranges, face_list, is, dL_dcolor, dL_ddepth, dL_dverts, dL_dverts_color,
                                          dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, hit_masks, hit_valid, st);
             return;

@@ -51,6 +51,8 @@ static_assert(8 * REC_PER_INSTR >= BM_CAND, "two LDS-direct instructions per wav
 #ifndef DM2_BF_BLOCKS
 #define DM2_BF_BLOCKS 4       // resident blocks per CU the register budget is set for (no spills at 127 VGPRs)
 #endif
+// POINT: aa_temperature == 0 (dm2_forward_point.hip left the masks): coverage 1 for every pair of the masks, no pool, no AA terms
+template <bool POINT>
 __global__ void __launch_bounds__(TILE_PIX, DM2_BF_BLOCKS)
 k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -60,7 +62,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                        const uint64_t* __restrict__ hit_masks, uint32_t* __restrict__ hit_valid,
                        const uint32_t* __restrict__ hit_base, const float* __restrict__ pool,
                        TieEntry* __restrict__ tie_queue, uint32_t tie_cap, bool check_mode STAMP_PARAM) {
-    if (check_mode && hit_valid[0] != 3u) return;                  // (caller did not know what the forward left: not masks + pool -> another kernel runs)
+    if (check_mode && hit_valid[0] != (POINT ? 1u : 3u)) return;                  // (caller did not know what the forward left: not masks + pool -> another kernel runs)
 
     __shared__ FaceRecB recs2[2][BM_CAND];                     // [buffer]: this chunk's candidates / the next chunk's
     __shared__ float acc[BM_CAND * BM_ACC];
@@ -154,7 +156,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // load issued before it -- vmcnt is in order -- and must not find this chunk's record loads in front of it)
         if (wid == 1 && (lane >> 1) < nc2)                         // lane: masks of (face lane / 2, waves 2 (lane & 1), + 1)
             glds16(hit_masks + walk_entry(nb + (lane >> 1)) * 4 + (lane & 1) * 2, &s_hit2[buf][0]);
-        if (wid == 3 && lane < nc2) glds4(hit_base + walk_entry(nb + lane), &s_hb2[buf][0]);
+        if (!POINT && wid == 3 && lane < nc2) glds4(hit_base + walk_entry(nb + lane), &s_hb2[buf][0]);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int r0 = (i * 4 + wid) * REC_PER_INSTR;          // this wave instruction's first record
@@ -199,7 +201,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         n = max(1, __popcll(__ballot((lane & 1) && inc <= TILE_PIX && (lane >> 1) < nc)));
         const int S = __builtin_amdgcn_readlane(inc, 2 * n - 1);
         if ((lane & 1) == (wid >> 1) && (lane >> 1) < BM_CAND) s_wbase[wid][lane >> 1] = (uint16_t)((wid & 1) ? b1 : b0);    // phase C: slot (face, this wave)
-        if ((lane & 1) == 0 && (lane >> 1) < BM_CAND) s_efirst[wid][lane >> 1] = (uint16_t)b0;                              // B2: the face's first pair
+        if (!POINT && (lane & 1) == 0 && (lane >> 1) < BM_CAND) s_efirst[wid][lane >> 1] = (uint16_t)b0;                              // B2: the face's first pair
         // pair lane -> slot: every non-empty slot that starts inside this wave's 64 pair lanes leaves a mark at its first
         // pair; a running maximum spreads it (slots and their first pairs grow together); the slot that covers the wave's
         // first lane comes from a ballot
@@ -242,7 +244,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             // (backward.cu:340-348) and the background term by it once more (backward.cu:396-401), so that one ulp of alpha is
             // ulp / (1 - alpha) of both; with the forward's own number a nearly opaque, nearly covering face is no special case.
             // Pool slot: the entry's first pair + this pair's place among the entry's pairs (the pool is in mask order).
-            ratio = pool[s_hb[j] + (uint32_t)(tid - (int)s_efirst[wid][j])];
+            ratio = POINT ? 1.0f : pool[s_hb[j] + (uint32_t)(tid - (int)s_efirst[wid][j])];
             const FaceRecB& fc = recs[j];
             BfPair out; out.alpha = 0.f; out.c0 = out.c1 = out.c2 = out.depth = 0.f; out.flags = 0;
             const f3 ro = {s_ray[q * 6], s_ray[q * 6 + 1], s_ray[q * 6 + 2]};
@@ -418,7 +420,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             bool tie_push = false;
             uint32_t tie_base = 0;
             unsigned long long tie_bal = 0;
-            {
+            if (!POINT) {
                 float g2[6];
                 bool tie = false;
                 {
@@ -481,7 +483,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         // ---- flush: lane = (entry, component); 8 entries per pass ------------------------------
         // Branch-free: every component's destination is  base + 4 (id * mult),  id one of the record's (face_id, vid[0..2]).
         const int comp = tid & 31;
-        if (comp < M_N) {
+        if (comp < (POINT ? M_AA : M_N)) {                                    // (no AA components at temperature 0)
             float* const basep = s_fl_base[comp];                                 // (per-component table, filled in the prologue)
             const int entry = s_fl_sel[comp];
             const bool corner = (entry & 0x80) != 0;                              // DM2_FLAG_AA_GRAD_TO_VERTS: an AA corner on its way to its vertex
@@ -549,7 +551,7 @@ k_aa_ties(dm2_render_desc d, const uint4* __restrict__ face_recs, const TieEntry
         // (runs by CONTIGUITY: the same face may come back further down the queue -- another tile's batch -- with other faces in
         // between; lane l - K is in lane l's run only if every lane between them is)
         const int key = valid ? (int)e.face : -1 - (int)lane, kv = (int)b, l16 = (int)(lane & 15u);
-        const int cont = ((l16 >= 1) & (dpp_shr_i<1>(key) == key) & (dpp_shr_i<1>(kv) == kv)) ? 1 : 0;     // continues the lane before
+        const int cont = (int)(l16 >= 1) & (int)(dpp_shr_i<1>(key) == key) & (int)(dpp_shr_i<1>(kv) == kv);   // continues the lane before (every DPP read executes)
         const int c2 = cont & dpp_shr_i<1>(cont), c4 = c2 & dpp_shr_i<2>(c2), c8 = c4 & dpp_shr_i<4>(c4);
         const bool s1 = cont != 0, s2 = (c2 != 0) & (l16 >= 2), s4 = (c4 != 0) & (l16 >= 4), s8 = (c8 != 0) & (l16 >= 8);
         const bool last = (l16 == 15) | (dpp_shl_i<1>(cont) == 0);
@@ -589,9 +591,16 @@ void launch_render_backward_fast(const dm2_render_desc& d, const uint2* ranges, 
                                  bool check_mode, hipStream_t st) {
     const uint32_t Tn = (uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B);
     const uint32_t cap = (uint32_t)(tie_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : tie_cap);
+    if (!(d.aa_temperature > 0.0f)) {                      // point-sampled coverage: the masks of dm2_forward_point.hip, nothing else
+        StageTimer tm(check_mode ? -1 : ST_BWD, st);
+        hipLaunchKernelGGL(k_render_backward_fast<true>, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+                           dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
+                           bs.hit_masks, bs.hit_valid, bs.hit_base, bs.pool, tie_queue, 0u, check_mode STAMP_ARG(1));
+        return;
+    }
     {
         StageTimer tm(check_mode ? -1 : ST_BWD, st);       // (under DM2_FWD_UNKNOWN the caller times the whole cascade)
-        hipLaunchKernelGGL(k_render_backward_fast, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
+        hipLaunchKernelGGL(k_render_backward_fast<false>, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, dL_dcolor, dL_ddepth,
                            dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense, dL_daa_face_verts,
                            bs.hit_masks, bs.hit_valid, bs.hit_base, bs.pool, tie_queue, cap, check_mode STAMP_ARG(1));
     }

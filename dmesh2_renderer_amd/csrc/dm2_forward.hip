@@ -124,7 +124,7 @@ int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const u
 #ifndef DM2_POINT_PER_PIXEL
         if (hit_masks && hit_valid) {
             launch_render_forward_point(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, hit_masks, hit_valid, st);
-            return DM2_FWD_NONE;                          // (the point-sampled backward checks its own masks on the device)
+            return DM2_FWD_POINT;
         }
 #endif
     }

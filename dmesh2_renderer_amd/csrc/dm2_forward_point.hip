@@ -39,9 +39,6 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    const float temp = d.aa_temperature;                           // == 0 (the launcher dispatches on it)
-    const float pix_area = 1.0f;
-
     bool done = !inside;
     float pT = 1.0f, T = 1.0f;
     uint32_t contributor = 0, last_contributor = 0;
@@ -59,10 +56,12 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
             f3 tuv = {0, 0, 0};
             const bool ok = ray_tri_intersection(ro, rd, p0, p1, p2, tuv);
-            float iuc, ivc; int code;
-            clamp_bary_uv(tuv.y, tuv.z, iuc, ivc, code);
-            const float ratio = mix_coverage(code, 0.0f / pix_area, temp);        // 1 inside, 0 outside at temperature 0
-            const bool hit = !done && ok && (ratio != 0.0f);
+            // At temperature 0 the coverage is 1 where the clamped barycentrics say "inside" (clamp_bary_uv's first region,
+            // auxiliary.h:294: code 0, u_c = u, v_c = v) and 0 everywhere else (forward.cu:375-381: mix_coverage(code, 0, 0)):
+            // the other six regions and the double-precision mix need not be evaluated to know that.
+            const float iuc = tuv.y, ivc = tuv.z;
+            const float ratio = 1.0f;
+            const bool hit = !done && ok && (iuc >= 0.0f) && (ivc >= 0.0f) && (iuc + ivc <= 1.0f);
             const unsigned long long bal = __ballot(hit);
             if (lane == 0) hit_masks[((int64_t)range.x + base + j) * 4 + wid] = bal;
             if (hit) {

@@ -200,6 +200,14 @@ void launch_render_backward(const dm2_render_desc& d, const uint2* ranges, const
 void launch_debug_aa_overlap(int variant, int64_t n, const float* tv, const float* te, const uint8_t* tz, const float* tr,
                              const float* tn, const float* tc, const float* pixmin, float* area, float* grad, int32_t* code,
                              hipStream_t st);
+hipError_t launch_exchange_mark(int B, int P, int F, int N, const int32_t* faces, const uint32_t* tiles_touched, uint8_t* flags,
+                                uint32_t* counts, hipStream_t st);
+hipError_t launch_exchange_pack(int B, int P, int F, int N, const uint8_t* flags, const uint32_t* counts, uint32_t* cursors,
+                                const float* dverts, const float* dcolor, const float* dopacity, const float* dintense, float* send,
+                                hipStream_t st);
+hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const float* recv, const uint32_t* recv_counts, int64_t rows,
+                                  float* slice_v, float* slice_f, hipStream_t st);
+int exchange_max_ranks();
 size_t tet_scratch_bytes(int64_t T);
 // tet_scratch (tet_scratch_bytes(T)) holds the packed per-tet records of the walk; nullptr = the reference-shaped walk
 void launch_layers(const dm2_layers_desc& d, const FaceState& fs, const uint2* ranges, const uint32_t* face_list,

@@ -147,6 +147,51 @@ def reduce_leaves_sparse(dverts, dcolor, dopacity, dintense, faces, touched, gro
     return gv[:, :3].contiguous(), gv[:, 3:].contiguous(), gf[:, 0].contiguous(), gf[:, 1:].t().contiguous()
 
 
+class DeviceExchange:
+    """The same exchange with its local work on the device (csrc/dm2_exchange.hip behind ``dm2_exchange_*``): three streaming
+    kernels instead of ~15 torch ops and a sort.  ``plan`` can run right after the forward (what a rank will send only depends
+    on the faces its band binned), so that the one host read-back -- the all-to-all's split sizes -- overlaps the backward;
+    ``reduce`` then packs, exchanges, sums and gathers.  Row order inside a segment is arbitrary; a row has a single
+    contributor but for faces that straddle a band edge, so results match ``reduce_leaves_sparse`` to fp32 rounding."""
+
+    def __init__(self, C, face_buf, faces, B, P, group=None):
+        import torch.distributed as dist
+        self.C, self.group = C, group
+        self.N = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.B, self.P, self.F = int(B), int(P), int(faces.shape[0])
+        self.flags, self.counts = C.exchange_mark(face_buf, faces, self.B, self.P, self.N)
+        self.cnt_recv = torch.empty_like(self.counts)
+        dist.all_to_all_single(self.cnt_recv, self.counts, group=group)          # what comes from where
+        # ONE read-back of (what goes where, what comes from where): issued now, looked at in reduce()
+        self._host = torch.empty((4 * self.N,), dtype=torch.int32, pin_memory=True)
+        self._host.copy_(torch.cat([self.counts.reshape(-1), self.cnt_recv.reshape(-1)]), non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+
+    def reduce(self, dverts, dcolor, dopacity, dintense):
+        import torch.distributed as dist
+        N, B, P, F = self.N, self.B, self.P, self.F
+        self._ev.synchronize()
+        h = self._host.tolist()
+        wf, wv = 2 + B, 7
+        in_split = [h[2 * d] * wf + h[2 * d + 1] * wv for d in range(N)]
+        out_split = [h[2 * N + 2 * d] * wf + h[2 * N + 2 * d + 1] * wv for d in range(N)]
+        rows_in = sum(h[2 * N:])
+        send = self.C.exchange_pack(self.flags, self.counts, sum(in_split), dverts, dcolor, dopacity, dintense)
+        recv = torch.empty((sum(out_split),), dtype=torch.float32, device=dverts.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+        slice_v, slice_f = self.C.exchange_unpack(recv, self.cnt_recv, rows_in, self.rank, B, P, F)
+        Ps, Fs = slice_v.shape[0], slice_f.shape[0]
+        mine = torch.cat([slice_v.reshape(-1), slice_f.reshape(-1)])
+        full = torch.empty((N * mine.numel(),), dtype=torch.float32, device=dverts.device)
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+        full = full.view(N, -1)
+        gv = full[:, : Ps * 6].reshape(N * Ps, 6)[:P]
+        gf = full[:, Ps * 6:].reshape(N * Fs, 1 + B)[:F]
+        return gv[:, :3].contiguous(), gv[:, 3:].contiguous(), gf[:, 0].contiguous(), gf[:, 1:].t().contiguous()
+
+
 class BandShardedOp:
     """Forward/backward of the render op on this rank's band of a full-frame call.
 
@@ -227,6 +272,15 @@ class BandShardedOp:
         B, F = self.args[8].shape[0], self.args[5].shape[0]
         return fn(self.fwd[7], B, F)
 
+    def plan_exchange(self, group=None):
+        """Call after ``forward`` (product backend, exchange="sparse"): marks the rows this rank will send and starts the
+        read-back of the all-to-all's split sizes, so that it is over by the time the backward has run."""
+        self._xchg = None
+        if self.fwd is not None and hasattr(self._C, "exchange_mark") and self.args[5].is_cuda:
+            a = self.args
+            self._xchg = DeviceExchange(self._C, self.fwd[7], a[5], a[8].shape[0], a[4].shape[0], group)
+        return self._xchg
+
     def backward_leaves(self, dL_dcolor_band, dL_ddepth_band, prep_inputs, group=None, prep_backward=None, exchange="dense"):
         """Band gradients -> gradients of the leaves, summed over ranks by a dense all-reduce of 24P + 4F + 4BF bytes
         (in two parts: colour / opacity / intensity start while the host-prep backward still runs, dverts follows).
@@ -263,6 +317,11 @@ class BandShardedOp:
         else:
             dverts += pb(verts, faces, mv, proj, width, height, g_verts_ndc=dndc, g_aa_face_verts=daa)
         if not dense:
+            if self.fwd is not None and hasattr(self._C, "exchange_mark") and faces.is_cuda and \
+                    dist.get_backend(group) != "gloo":       # (gloo has no all-to-all on device tensors)
+                x = getattr(self, "_xchg", None) or self.plan_exchange(group)
+                self._xchg = None
+                return x.reduce(dverts, dcolor, dopacity, dintense)
             touched = self.touched_faces()
             if touched is None:      # backend without the scratch accessor: any face or vertex row that is not exactly zero
                 fl = faces.long()

@@ -121,6 +121,7 @@ enum {
 #define DM2_FWD_NONE 1     /* nothing (DM2_FLAG_NO_BACKWARD, DM2_FLAG_LEGACY_KERNELS): the per-pixel walk recomputes everything */
 #define DM2_FWD_MASKS 2    /* per list entry the pixels it blended into: the backward re-clips those pairs exactly */
 #define DM2_FWD_POOL 3     /* masks + pair pool: the default -- no clip for an area, Jacobians without a polygon */
+#define DM2_FWD_POINT 4    /* aa_temperature == 0: per list entry the pixels whose rays hit it (point-sampled coverage) */
 
 int dm2_abi_version(void);
 const char* dm2_last_error(void);
@@ -153,8 +154,8 @@ int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_b
  * Pair pool: when binning_bytes >= DM2_SCRATCH_BINNING bytes + DM2_SCRATCH_PAIR_POOL bytes for pair_bound, the
  * composite also leaves the coverage ratio (forward.cu:375-378) of every blended pair in the appended part and
  * *forward_mode is DM2_FWD_POOL; otherwise DM2_FWD_MASKS (a caller that finds pair_bound too large for its memory
- * simply appends nothing), or DM2_FWD_NONE under DM2_FLAG_NO_BACKWARD / DM2_FLAG_LEGACY_KERNELS / aa_temperature 0
- * (the point-sampled kernels keep their own masks).  forward_mode may be NULL. */
+ * simply appends nothing), DM2_FWD_POINT at aa_temperature 0, or DM2_FWD_NONE under DM2_FLAG_NO_BACKWARD /
+ * DM2_FLAG_LEGACY_KERNELS.  forward_mode may be NULL. */
 int dm2_forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, int64_t pair_bound,
                     void* face_scratch, size_t face_bytes,
                     void* binning_scratch, size_t binning_bytes,
@@ -256,6 +257,26 @@ int dm2_prepare_faces(const dm2_prep_desc* d, void* stream);
 int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc, const float* g_verts_image,
                                const float* g_aa_face_verts, float* image_grad_scratch, float* g_verts,
                                void* stream);
+
+/* Device side of the sparse leaf-gradient exchange of a frame sharded by tile rows over N ranks (the
+ * collectives themselves belong to the caller: dmesh2_renderer_amd/sharding.py drives torch.distributed / RCCL).  Rows are
+ * owned by contiguous id ranges: face f by rank f / ceil(F/N), vertex v by rank v / ceil(P/N).
+ *   dm2_exchange_mark    after dm2_forward*: flags (P + F bytes of caller scratch: F face flags, then P vertex flags) mark the
+ *                        faces this rank's tile lists hold (any view) and their vertices; counts (2 N uint32, device):
+ *                        [2 o] faces / [2 o + 1] vertices flagged in owner o's range = the rows this rank will send to o.
+ *   dm2_exchange_pack    after the backward: the send buffer, per owner o [counts[2 o] rows of (2 + B) floats: id bits, dopacity,
+ *                        dintense(b = 0..B-1) | counts[2 o + 1] rows of 7 floats: id bits, dverts(3), dverts_color(3)];
+ *                        cursors: 2 N uint32 of scratch.  Rows of one segment in no particular order.
+ *   dm2_exchange_unpack  owner `rank`: recv holds, per source s, [recv_counts[2 s] face rows | recv_counts[2 s + 1] vertex rows]
+ *                        (`rows` rows in all); they are summed into slice_v (ceil(P/N), 6) and slice_f (ceil(F/N), 1 + B),
+ *                        which the call zero-fills first. */
+int dm2_exchange_mark(int32_t B, int32_t P, int32_t F, int32_t N, const int32_t* faces, const void* face_scratch, size_t face_bytes,
+                      uint8_t* flags, uint32_t* counts, void* stream);
+int dm2_exchange_pack(int32_t B, int32_t P, int32_t F, int32_t N, const uint8_t* flags, const uint32_t* counts, uint32_t* cursors,
+                      const float* dverts, const float* dverts_color, const float* dfaces_opacity, const float* dfaces_intense,
+                      float* send, void* stream);
+int dm2_exchange_unpack(int32_t B, int32_t P, int32_t F, int32_t N, int32_t rank, const float* recv, const uint32_t* recv_counts,
+                        int64_t rows, float* slice_v, float* slice_f, void* stream);
 
 /* Introspection for tests/bench: copy pieces of the scratch state to caller
  * (device) buffers.  what: 0 ranges (B*tiles*2 u32, from image scratch),

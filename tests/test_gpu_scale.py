@@ -280,3 +280,67 @@ def test_touched_faces_accessor_matches_the_lists():
     flist = _C.debug_fetch(1, N, Tn, out[0], out[8], torch.int32, out[0]).cpu().numpy()
     want = np.zeros(F, bool); want[flist] = True
     assert np.array_equal(touched, want) and 0 < touched.sum() < F
+
+
+@pytest.mark.parametrize("N", [2, 3, 8])
+def test_device_exchange_kernels_emulated_ranks(N):
+    """dm2_exchange_mark / _pack / _unpack (csrc/dm2_exchange.hip), N ranks emulated on one GPU with the all-to-all routed by
+    hand: every rank renders its band of the same frame, packs the touched rows of its partial leaf gradients per owner; every
+    owner sums what it is sent; the gathered slices must equal the dense sum of the partials, and the rows a rank sends must be
+    exactly the rows the torch formulation (sharding.reduce_leaves_sparse) would send."""
+    from dmesh2_renderer_amd import _C
+    from dmesh2_renderer_amd.sharding import BandShardedOp
+    b = _bench()
+    dev = torch.device("cuda", 0)
+    args, dLc, dLd, (W, H, F) = b.build_inputs("cfg2", dev, 0, 1)
+    faces = args[5]
+    B, P = args[8].shape[0], args[4].shape[0]
+    Ps, Fs = -(-P // N), -(-F // N)
+    parts, sends, counts = [], [], []
+    for r in range(N):
+        op = BandShardedOp(args, N, r)
+        op.world_size = 1
+        op.forward()
+        g = op.backward(dLc[:, op.y0:op.y0 + op.rows].contiguous(), dLd[:, op.y0:op.y0 + op.rows].contiguous(), reduce=False)
+        leaves = (g[0], g[1], g[2], g[4])                     # dverts, dverts_color, dfaces_opacity, dfaces_intense
+        parts.append([x.clone() for x in leaves])
+        flags, cnt = _C.exchange_mark(op.fwd[7], faces, B, P, N)
+        touched = _C.touched_faces(op.fwd[7], B, F)
+        assert torch.equal(flags[:F].bool(), touched)
+        vflag = torch.zeros(P, dtype=torch.bool, device=dev); vflag[faces[touched].reshape(-1).long()] = True
+        assert torch.equal(flags[F:].bool(), vflag)
+        ch = cnt.cpu().tolist()
+        for o in range(N):                                     # rows per owner = flagged ids in the owner's range
+            assert ch[o][0] == int(touched[o * Fs:(o + 1) * Fs].sum()) and ch[o][1] == int(vflag[o * Ps:(o + 1) * Ps].sum())
+        total = sum(c[0] * (2 + B) + c[1] * 7 for c in ch)
+        send = _C.exchange_pack(flags, cnt, total, *leaves)
+        # segment by segment: the set of rows == the flagged rows of the owner's range, values included
+        off = 0
+        for o in range(N):
+            nf, nv = ch[o]
+            fr = send[off:off + nf * (2 + B)].view(nf, 2 + B); off += nf * (2 + B)
+            vr = send[off:off + nv * 7].view(nv, 7); off += nv * 7
+            fid = fr[:, 0].contiguous().view(torch.int32).long(); vid = vr[:, 0].contiguous().view(torch.int32).long()
+            want_f = torch.nonzero(touched[o * Fs:(o + 1) * Fs]).flatten() + o * Fs
+            want_v = torch.nonzero(vflag[o * Ps:(o + 1) * Ps]).flatten() + o * Ps
+            assert torch.equal(torch.sort(fid).values, want_f) and torch.equal(torch.sort(vid).values, want_v)
+            assert torch.equal(fr[:, 1], leaves[2][fid]) and torch.equal(fr[:, 2:], leaves[3][:, fid].t())
+            assert torch.equal(vr[:, 1:4], leaves[0][vid]) and torch.equal(vr[:, 4:], leaves[1][vid])
+        sends.append(send); counts.append(ch)
+    # the all-to-all, by hand: owner o receives, source by source, that source's segment for o
+    dense = [sum(p[i] for p in parts) for i in range(4)]
+    gv, gf = [], []
+    for o in range(N):
+        chunks, rc = [], []
+        for s_ in range(N):
+            off = sum(counts[s_][k][0] * (2 + B) + counts[s_][k][1] * 7 for k in range(o))
+            n = counts[s_][o][0] * (2 + B) + counts[s_][o][1] * 7
+            chunks.append(sends[s_][off:off + n]); rc.append(counts[s_][o])
+        recv = torch.cat(chunks) if chunks else torch.empty(0, device=dev)
+        rct = torch.tensor(rc, dtype=torch.int32, device=dev)
+        sv, sf = _C.exchange_unpack(recv, rct, sum(c[0] + c[1] for c in rc), o, B, P, F)
+        gv.append(sv); gf.append(sf)
+    gv = torch.cat(gv)[:P]; gf = torch.cat(gf)[:F]
+    got = (gv[:, :3], gv[:, 3:], gf[:, 0], gf[:, 1:].t())
+    for a, d in zip(got, dense):
+        assert rel_linf(a.cpu().numpy(), d.cpu().numpy()) <= 1e-6

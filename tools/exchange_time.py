@@ -49,7 +49,23 @@ def main():
     leaves = [x.clone() for x in leaves]
     res["touched_faces()"] = timed(op.touched_faces)
     t = op.touched_faces()
-    res["reduce_leaves_sparse, one-rank group (local packing + two all-to-all + all-gather to self)"] = timed(lambda: reduce_leaves_sparse(*leaves, args[5], t))
+    res["reduce_leaves_sparse (torch ops), one-rank group (local packing + two all-to-all + all-gather to self)"] = timed(lambda: reduce_leaves_sparse(*leaves, args[5], t))
+    # the same exchange with its local work in HIP kernels (csrc/dm2_exchange.hip): plan (mark + count + split-size read-back;
+    # overlaps the backward in a real step) and reduce (pack, all-to-all, unpack, all-gather)
+    from dmesh2_renderer_amd.sharding import DeviceExchange
+    B, P = args[8].shape[0], args[4].shape[0]
+    res["DeviceExchange: plan (after the forward; its read-back overlaps the backward)"] = timed(lambda: DeviceExchange(_C, op.fwd[7], args[5], B, P))
+    x = DeviceExchange(_C, op.fwd[7], args[5], B, P)
+    res["DeviceExchange: reduce (pack + all-to-all + unpack + all-gather, one-rank group)"] = timed(lambda: x.reduce(*leaves))
+    out = x.reduce(*leaves)
+    ref = reduce_leaves_sparse(*leaves, args[5], t)
+    assert all(torch.allclose(a, b, rtol=0, atol=1e-6 * float(b.abs().max())) for a, b in zip(out, ref)), "device exchange != torch exchange"
+    flags, cnt = _C.exchange_mark(op.fwd[7], args[5], B, P, 1)
+    tot = int((cnt[:, 0] * (2 + B) + cnt[:, 1] * 7).sum())
+    res["  of which: dm2_exchange_mark (2 memsets + 2 kernels)"] = timed(lambda: _C.exchange_mark(op.fwd[7], args[5], B, P, 1))
+    res["  of which: dm2_exchange_pack"] = timed(lambda: _C.exchange_pack(flags, cnt, tot, *leaves))
+    send = _C.exchange_pack(flags, cnt, tot, *leaves)
+    res["  of which: dm2_exchange_unpack (2 memsets + 1 kernel)"] = timed(lambda: _C.exchange_unpack(send, cnt, int(cnt.sum()), 0, B, P, F))
     span = torch.cat([x.reshape(-1) for x in leaves])
     res["dense: all_reduce of the packed leaves, one-rank group"] = timed(lambda: dist.all_reduce(span))
     print(f"cfg4, band 0 of {bands} ({op.rows} rows), touched faces {int(t.sum())} of {F}")

@@ -467,6 +467,21 @@ def main():
         for _ in range(reps):
             step(timed_exchange=True)
 
+    # the same step with all 21 arguments of the reference's boundary taken as they are (the six AA tables read from the
+    # tensors the caller built, not derived inside the op's plan)
+    strict_ms = None
+    if world == 1 and op.tables_from_image:
+        op21 = BandShardedOp(args, 1, 0, tables_from_image=False)
+        for _ in range(3):
+            op21.forward(); op21.backward(dLc_b, dLd_b)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(max(5, opt.steps // 2)):
+            op21.forward(); op21.backward(dLc_b, dLd_b)
+        torch.cuda.synchronize()
+        strict_ms = (time.perf_counter() - ts) / max(5, opt.steps // 2) * 1e3
+        del op21
+
     R = op.fwd[0] if op.fwd is not None else 0
     B, P = args[8].shape[0], args[4].shape[0]
     N_band = B * op.rows * W
@@ -511,6 +526,9 @@ def main():
             "workload": f"Renderer forward+backward {W}x{H}{' windows of 1920x1080 cameras' if opt.config in VIEWS else ''}, {F} triangles (soup, P=3F), B={B}, aa_temperature={AA_TEMPERATURE}, K=20, "
                         f"AA visibility gradients on ({'BASELINE configs[3]' if opt.config == 'cfg4' else opt.config})",
             "sharding": "single GPU" if world == 1 else f"tile-row bands x{world}, exchange={reduce_mode}",
+            "op_path": ("the module's default: the op's plan builds the six AA tables from verts_image (DM2_FLAG_TABLES_FROM_IMAGE), as under "
+                        "Renderer with its fused host prep" if op.tables_from_image else "all 21 arguments of the reference's boundary read as given"),
+            "ms_per_step_21_argument_path": None if strict_ms is None else round(strict_ms, 4),
             "num_rendered_rank0": int(R), "grad_Mtris_per_s": round(F / bwd_ms / 1e3, 2),
             "ms_per_step_median_hipevent_rank0": round(ms_median, 4),
             "stage_ms_rank0": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -362,10 +362,10 @@ def last_forward_mode():
 
 
 def _pool_budget(N, R):
-    """Pairs the shim is willing to give pool room to (4 B each in the binning buffer + 16 B each of backward scratch): a
-    frame whose plan counts more candidate pairs than this -- thousands of screen-filling faces -- keeps blend masks only
-    and its backward re-clips (DM2_FWD_MASKS)."""
-    return max(64 * N, 8 * R, 1 << 22)
+    """Pairs the shim is willing to give pool room to (4 B each in the binning buffer + 16 B each of backward scratch, 8 GB at
+    the cap): a frame whose plan counts more candidate pairs than this -- hundreds of faces over every pixel of a large image,
+    thousands of screen-filling faces -- keeps blend masks only and its backward re-clips (DM2_FWD_MASKS)."""
+    return min(max(256 * N, 16 * R, 1 << 24), 400_000_000)
 
 
 def _analytic(B, dev):
@@ -698,15 +698,17 @@ def exchange_pack(flags, counts, total_floats, dverts, dcolor, dopacity, dintens
 
 
 def exchange_unpack(recv, recv_counts, rows, rank, B, P, F):
-    """-> (slice_v (ceil(P/N), 6), slice_f (ceil(F/N), 1 + B)): the owner's sums of the received rows."""
+    """-> (slice_v (ceil(P/N), 6), slice_f (ceil(F/N), 1 + B)): the owner's sums of the received rows.  recv_counts: (N, 2)
+    int32 on the HOST (a list of pairs will do)."""
     lib = load_library()
-    dev = _require_gpu(recv, recv_counts)
+    dev = _require_gpu(recv)
+    recv_counts = torch.as_tensor(recv_counts, dtype=torch.int32, device="cpu").reshape(-1, 2).contiguous()
     N = recv_counts.shape[0]
     Ps, Fs = -(-P // N), -(-F // N)
     slice_v = torch.empty((Ps, 6), dtype=torch.float32, device=dev)
     slice_f = torch.empty((Fs, 1 + B), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        if lib.dm2_exchange_unpack(B, P, F, N, int(rank), _ptr(recv), _ptr(_c(recv_counts, torch.int32)), int(rows), _ptr(slice_v), _ptr(slice_f),
+        if lib.dm2_exchange_unpack(B, P, F, N, int(rank), _ptr(recv), ctypes.c_void_p(recv_counts.data_ptr()), int(rows), _ptr(slice_v), _ptr(slice_f),
                                    _stream(dev)):
             raise _err(lib, "dm2_exchange_unpack")
     return slice_v, slice_f

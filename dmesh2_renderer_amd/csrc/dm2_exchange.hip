@@ -10,10 +10,10 @@
 //                                their vertices, count the flagged rows per owner -- the all-to-all's split sizes, which
 //                                the host can read back while the backward still runs
 //   k_xchg_pack                  after the backward: [id | dopacity | dintense(B)] and [id | dverts(3) | dcolor(3)] rows into the
-//                                send buffer, per owner [face rows | vertex rows]; places inside a segment by wave-aggregated
-//                                atomics (the lanes of a wave mostly share one owner: one atomic per wave and owner)
-//   k_xchg_unpack                owner: every received row is added to the dense slice (fp32 atomics; a row has one contributor
-//                                but for the faces that straddle a band edge)
+//                                send buffer, per owner [face rows | vertex rows]; places inside a segment: one global atomic per
+//                                block of 8192 ids and owner, LDS cursors inside the block
+//   k_xchg_unpack                owner: every received row is added to the dense slice, one launch per source (rows of one source
+//                                have distinct ids: plain adds, and the same summation order on every rank)
 //
 // All HBM streaming: 4 B of flags + ~40 B per touched row; tools/exchange_time.py times them against the torch formulation
 // they replace (15 torch kernels + a sort: 0.6-0.8 ms per step at 1080p / 1 M faces).
@@ -27,12 +27,10 @@ namespace {
 
 constexpr int XCHG_MAX_RANKS = 64;
 
-__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-// One count per active lane into cnt[2 * owner + kind], the lanes of a wave that share an owner through ONE atomic;
-// returns the lane's place (as its own atomicAdd(.., 1) would).  Call with the whole wave (act = the lane has a row).
-__device__ __forceinline__ uint32_t wave_owner_place(uint32_t* cnt, uint32_t slot, bool act) {
-    const int lane = lane_id();
+// One count per active lane into cnt[slot] (LDS), the lanes of a wave that share a slot through ONE atomic (neighbouring ids share
+// their owner: one or two distinct slots per wave); returns the lane's place, as its own atomicAdd(.., 1) would.  Whole waves only.
+__device__ __forceinline__ uint32_t wave_slot_place(uint32_t* cnt, uint32_t slot, bool act) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     unsigned long long todo = __ballot(act);
     uint32_t place = 0;
     while (todo) {
@@ -48,6 +46,10 @@ __device__ __forceinline__ uint32_t wave_owner_place(uint32_t* cnt, uint32_t slo
     return place;
 }
 
+constexpr int XCHG_IDS_PER_BLOCK = 8192;      // a block takes a contiguous chunk of ids: a few hundred global atomics per call in all
+                                              // (one atomic per wave on the 2 N counters -- the same few addresses -- was 0.7 ms: atomics on
+                                              // one address are serialised by the L2)
+
 __global__ void __launch_bounds__(256)
 k_xchg_mark(int B, int F, const int32_t* __restrict__ faces, const uint32_t* __restrict__ tiles_touched,
             uint8_t* __restrict__ flag_f, uint8_t* __restrict__ flag_v) {
@@ -60,71 +62,90 @@ k_xchg_mark(int B, int F, const int32_t* __restrict__ faces, const uint32_t* __r
     flag_v[faces[3 * (int64_t)f]] = 1; flag_v[faces[3 * (int64_t)f + 1]] = 1; flag_v[faces[3 * (int64_t)f + 2]] = 1;
 }
 
+// flagged ids of [i0, i0 + XCHG_IDS_PER_BLOCK) per owner, counted in LDS first
 __global__ void __launch_bounds__(256)
-k_xchg_count(int P, int F, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
+k_xchg_count(int P, int F, int N, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
              uint32_t* __restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (whole waves: the lanes past the end stay for the ballots)
-    const bool af = i < F && flag_f[i], av = i < P && flag_v[i];
-    wave_owner_place(counts, 2u * (uint32_t)(af ? i / Fs : 0), af);
-    wave_owner_place(counts, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
+    __shared__ uint32_t s_cnt[2 * XCHG_MAX_RANKS];
+    for (int k = threadIdx.x; k < 2 * N; k += 256) s_cnt[k] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK;
+    for (int k = threadIdx.x; k < XCHG_IDS_PER_BLOCK; k += 256) {      // (whole waves: the trip count is uniform)
+        const int64_t i = i0 + k;
+        const bool af = i < F && flag_f[i], av = i < P && flag_v[i];
+        wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
+        wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * N; k += 256) if (s_cnt[k]) atomicAdd(counts + k, s_cnt[k]);
 }
 
-// element offset of owner o's segment in the send buffer: per owner [nf rows of (2 + B) | nv rows of 7]
-__device__ __forceinline__ uint32_t seg_start(const uint32_t* __restrict__ counts, int o, int B) {
-    uint32_t off = 0;
-    for (int k = 0; k < o; k++) off += counts[2 * k] * (uint32_t)(2 + B) + counts[2 * k + 1] * 7u;
-    return off;
-}
-
+// the rows of the block's chunk of ids: counted per owner in LDS, ONE global atomic per (block, owner, kind) reserves their
+// places in the owner's segment, the rows take them in whatever order the LDS cursor hands out
 __global__ void __launch_bounds__(256)
-k_xchg_pack(int B, int P, int F, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
+k_xchg_pack(int B, int P, int F, int N, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, const float* __restrict__ dverts,
             const float* __restrict__ dcolor, const float* __restrict__ dopacity, const float* __restrict__ dintense,
             float* __restrict__ send) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool af = i < F && flag_f[i], av = i < P && flag_v[i];
-    const int of = af ? (int)(i / Fs) : 0, ov = av ? (int)(i / Ps) : 0;
-    const uint32_t pf = wave_owner_place(cursors, 2u * (uint32_t)of, af);
-    const uint32_t pv = wave_owner_place(cursors, 2u * (uint32_t)ov + 1u, av);
-    if (af) {
-        float* dst = send + seg_start(counts, of, B) + (size_t)pf * (size_t)(2 + B);
-        dst[0] = __int_as_float((int)i);                               // (the id's bits travel in a float slot)
-        dst[1] = dopacity[i];
-        for (int b = 0; b < B; b++) dst[2 + b] = dintense[(int64_t)b * F + i];
+    __shared__ uint32_t s_cnt[2 * XCHG_MAX_RANKS], s_base[2 * XCHG_MAX_RANKS], s_seg[XCHG_MAX_RANKS + 1];
+    for (int k = threadIdx.x; k < 2 * N; k += 256) s_cnt[k] = 0;
+    if (threadIdx.x == 0) {
+        uint32_t off = 0;
+        for (int o = 0; o < N; o++) { s_seg[o] = off; off += counts[2 * o] * (uint32_t)(2 + B) + counts[2 * o + 1] * 7u; }
     }
-    if (av) {
-        float* dst = send + seg_start(counts, ov, B) + (size_t)counts[2 * ov] * (size_t)(2 + B) + (size_t)pv * 7u;
-        dst[0] = __int_as_float((int)i);
-        dst[1] = dverts[3 * i]; dst[2] = dverts[3 * i + 1]; dst[3] = dverts[3 * i + 2];
-        dst[4] = dcolor[3 * i]; dst[5] = dcolor[3 * i + 1]; dst[6] = dcolor[3 * i + 2];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK;
+    for (int k = threadIdx.x; k < XCHG_IDS_PER_BLOCK; k += 256) {
+        const int64_t i = i0 + k;
+        const bool af = i < F && flag_f[i], av = i < P && flag_v[i];
+        wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
+        wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * N; k += 256) { s_base[k] = s_cnt[k] ? atomicAdd(cursors + k, s_cnt[k]) : 0u; s_cnt[k] = 0; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < XCHG_IDS_PER_BLOCK; k += 256) {
+        const int64_t i = i0 + k;
+        const bool af = i < F && flag_f[i], av = i < P && flag_v[i];
+        const uint32_t pfl = wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
+        const uint32_t pvl = wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
+        if (af) {
+            const int o = (int)(i / Fs);
+            const uint32_t pf = s_base[2 * o] + pfl;
+            float* dst = send + s_seg[o] + (size_t)pf * (size_t)(2 + B);
+            dst[0] = __int_as_float((int)i);                           // (the id's bits travel in a float slot)
+            dst[1] = dopacity[i];
+            for (int b = 0; b < B; b++) dst[2 + b] = dintense[(int64_t)b * F + i];
+        }
+        if (av) {
+            const int o = (int)(i / Ps);
+            const uint32_t pv = s_base[2 * o + 1] + pvl;
+            float* dst = send + s_seg[o] + (size_t)counts[2 * o] * (size_t)(2 + B) + (size_t)pv * 7u;
+            dst[0] = __int_as_float((int)i);
+            dst[1] = dverts[3 * i]; dst[2] = dverts[3 * i + 1]; dst[3] = dverts[3 * i + 2];
+            dst[4] = dcolor[3 * i]; dst[5] = dcolor[3 * i + 1]; dst[6] = dcolor[3 * i + 2];
+        }
     }
 }
 
-// recv: per source s [nf_s rows of (2 + B) | nv_s rows of 7], recv_counts[2 s], [2 s + 1]; one thread per row
+// One source at a time (launch order = source order: the same summation order on every rank): the nf face rows and nv
+// vertex rows of one source carry distinct ids, so plain read-add-write is race free within a launch.
 __global__ void __launch_bounds__(256)
-k_xchg_unpack(int B, int N, int rank, int Ps, int Fs, const float* __restrict__ recv, const uint32_t* __restrict__ recv_counts,
+k_xchg_unpack(int B, int rank, int Ps, int Fs, const float* __restrict__ rows_f, uint32_t nf, const float* __restrict__ rows_v, uint32_t nv,
               float* __restrict__ slice_v, float* __restrict__ slice_f) {
-    int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    size_t off = 0;
-    for (int s = 0; s < N; s++) {
-        const uint32_t nf = recv_counts[2 * s], nv = recv_counts[2 * s + 1];
-        if (r < (int64_t)nf) {
-            const float* row = recv + off + (size_t)r * (size_t)(2 + B);
-            const int64_t id = (int64_t)__float_as_int(row[0]) - (int64_t)rank * Fs;
-            if (id < 0 || id >= Fs) return;                            // (a row that is not this owner's: never sent by a correct peer)
-            for (int k = 0; k < 1 + B; k++) atomicAdd(slice_f + id * (1 + B) + k, row[1 + k]);
-            return;
-        }
-        r -= nf; off += (size_t)nf * (size_t)(2 + B);
-        if (r < (int64_t)nv) {
-            const float* row = recv + off + (size_t)r * 7u;
-            const int64_t id = (int64_t)__float_as_int(row[0]) - (int64_t)rank * Ps;
-            if (id < 0 || id >= Ps) return;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < (int64_t)nf) {
+        const float* row = rows_f + (size_t)r * (size_t)(2 + B);
+        const int64_t id = (int64_t)__float_as_int(row[0]) - (int64_t)rank * Fs;
+        if (id >= 0 && id < Fs)                                        // (a row that is not this owner's: never sent by a correct peer)
+            for (int k = 0; k < 1 + B; k++) slice_f[id * (1 + B) + k] += row[1 + k];
+    } else if (r - nf < (int64_t)nv) {
+        const float* row = rows_v + (size_t)(r - nf) * 7u;
+        const int64_t id = (int64_t)__float_as_int(row[0]) - (int64_t)rank * Ps;
+        if (id >= 0 && id < Ps) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) atomicAdd(slice_v + id * 6 + k, row[1 + k]);
-            return;
+            for (int k = 0; k < 6; k++) slice_v[id * 6 + k] += row[1 + k];
         }
-        r -= nv; off += (size_t)nv * 7u;
     }
 }
 
@@ -141,7 +162,7 @@ hipError_t launch_exchange_mark(int B, int P, int F, int N, const int32_t* faces
     uint8_t* flag_f = flags; uint8_t* flag_v = flags + F;
     hipLaunchKernelGGL(k_xchg_mark, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, B, F, faces, tiles_touched, flag_f, flag_v);
     const int64_t m = P > F ? P : F;
-    hipLaunchKernelGGL(k_xchg_count, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, P, F, Ps, Fs, flag_f, flag_v, counts);
+    hipLaunchKernelGGL(k_xchg_count, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(256), 0, st, P, F, N, Ps, Fs, flag_f, flag_v, counts);
     return hipSuccess;
 }
 
@@ -153,12 +174,13 @@ hipError_t launch_exchange_pack(int B, int P, int F, int N, const uint8_t* flags
     if (F == 0 || P == 0) return hipSuccess;
     const int Fs = (F + N - 1) / N, Ps = (P + N - 1) / N;
     const int64_t m = P > F ? P : F;
-    hipLaunchKernelGGL(k_xchg_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, B, P, F, Ps, Fs, flags, flags + F, counts, cursors,
-                       dverts, dcolor, dopacity, dintense, send);
+    hipLaunchKernelGGL(k_xchg_pack, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(256), 0, st, B, P, F, N, Ps, Fs, flags, flags + F,
+                       counts, cursors, dverts, dcolor, dopacity, dintense, send);
     return hipSuccess;
 }
 
-hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const float* recv, const uint32_t* recv_counts, int64_t rows,
+// recv_counts_host: the owner's HOST copy of the (N, 2) row counts (the caller read them back for the all-to-all's split sizes)
+hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const float* recv, const uint32_t* recv_counts_host, int64_t rows,
                                   float* slice_v, float* slice_f, hipStream_t st) {
     const int Fs = (F + N - 1) / N, Ps = (P + N - 1) / N;
     hipError_t e = hipMemsetAsync(slice_v, 0, (size_t)Ps * 6 * sizeof(float), st);
@@ -166,7 +188,14 @@ hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const fl
     e = hipMemsetAsync(slice_f, 0, (size_t)Fs * (1 + B) * sizeof(float), st);
     if (e != hipSuccess) return e;
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_xchg_unpack, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, B, N, rank, Ps, Fs, recv, recv_counts, slice_v, slice_f);
+    size_t off = 0;
+    for (int s = 0; s < N; s++) {
+        const uint32_t nf = recv_counts_host[2 * s], nv = recv_counts_host[2 * s + 1];
+        const float* rows_f = recv + off; off += (size_t)nf * (size_t)(2 + B);
+        const float* rows_v = recv + off; off += (size_t)nv * 7u;
+        const int64_t n = (int64_t)nf + nv;
+        if (n > 0) hipLaunchKernelGGL(k_xchg_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, rank, Ps, Fs, rows_f, nf, rows_v, nv, slice_v, slice_f);
+    }
     return hipSuccess;
 }
 

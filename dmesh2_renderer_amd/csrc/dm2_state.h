@@ -205,7 +205,7 @@ hipError_t launch_exchange_mark(int B, int P, int F, int N, const int32_t* faces
 hipError_t launch_exchange_pack(int B, int P, int F, int N, const uint8_t* flags, const uint32_t* counts, uint32_t* cursors,
                                 const float* dverts, const float* dcolor, const float* dopacity, const float* dintense, float* send,
                                 hipStream_t st);
-hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const float* recv, const uint32_t* recv_counts, int64_t rows,
+hipError_t launch_exchange_unpack(int B, int P, int F, int N, int rank, const float* recv, const uint32_t* recv_counts_host, int64_t rows,
                                   float* slice_v, float* slice_f, hipStream_t st);
 int exchange_max_ranks();
 size_t tet_scratch_bytes(int64_t T);

@@ -181,7 +181,7 @@ class DeviceExchange:
         send = self.C.exchange_pack(self.flags, self.counts, sum(in_split), dverts, dcolor, dopacity, dintense)
         recv = torch.empty((sum(out_split),), dtype=torch.float32, device=dverts.device)
         dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
-        slice_v, slice_f = self.C.exchange_unpack(recv, self.cnt_recv, rows_in, self.rank, B, P, F)
+        slice_v, slice_f = self.C.exchange_unpack(recv, [h[2 * N + 2 * d:2 * N + 2 * d + 2] for d in range(N)], rows_in, self.rank, B, P, F)
         Ps, Fs = slice_v.shape[0], slice_f.shape[0]
         mine = torch.cat([slice_v.reshape(-1), slice_f.reshape(-1)])
         full = torch.empty((N * mine.numel(),), dtype=torch.float32, device=dverts.device)
@@ -200,10 +200,15 @@ class BandShardedOp:
     are derived by slicing the ray tensors and moving ``patch_min``.
     """
 
-    def __init__(self, full_args, world_size: int, rank: int, backend=None):
+    def __init__(self, full_args, world_size: int, rank: int, backend=None, tables_from_image=None):
         from . import _C
         self._C = backend or _C
         self.world_size, self.rank = world_size, rank
+        # the product's default path (Renderer with the fused prep): the six AA tables are not handed over but built inside
+        # the op's plan from verts_image (DM2_FLAG_TABLES_FROM_IMAGE): a rank's plan then reads ~50 B per face instead of ~170
+        if tables_from_image is None:
+            tables_from_image = hasattr(self._C, "tables_from_image") and torch.is_tensor(full_args[9]) and full_args[9].is_cuda
+        self.tables_from_image = bool(tables_from_image)
         # the product backend can hand the AA-corner gradients back per vertex (DM2_FLAG_AA_GRAD_TO_VERTS; announced in the
         # forward, used by backward_leaves): no (B,F,3,2) scatter pass over all faces on every rank
         self.routed = hasattr(self._C, "aa_grad_to_verts")
@@ -216,8 +221,17 @@ class BandShardedOp:
         a[3] = self.rows
         a[19] = a[19][:, self.y0:self.y0 + self.rows].contiguous()
         a[20] = a[20][:, self.y0:self.y0 + self.rows].contiguous()
+        if self.tables_from_image:
+            Bv = a[8].shape[0]
+            for k in range(12, 17):
+                a[k] = torch.empty((Bv, 0, 3, 2), dtype=a[k].dtype, device=a[k].device)       # placeholders, never read
+            a[17] = torch.empty((Bv, 0, 3), dtype=a[17].dtype, device=a[17].device)
         self.args = a
         self.fwd = None
+
+    def _ctx(self):
+        import contextlib
+        return self._C.tables_from_image(True) if self.tables_from_image else contextlib.nullcontext()
 
     def forward(self):
         """-> (color, depth) of this rank's band: rows [y0, y0+rows) of the frame."""
@@ -228,7 +242,7 @@ class BandShardedOp:
             self.fwd = None
             return torch.zeros((B, 0, W, 3), device=dev), torch.zeros((B, 0, W), device=dev)
         if self.routed:          # (the forward's packed records note the CCW reorder the routed backward needs)
-            with self._C.aa_grad_to_verts(True):
+            with self._C.aa_grad_to_verts(True), self._ctx():
                 self.fwd = self._C.render_forward_cuda(*self.args)
         else:
             self.fwd = self._C.render_forward_cuda(*self.args)
@@ -251,12 +265,13 @@ class BandShardedOp:
         else:
             f = self.fwd
             if aa_to_verts:
-                with self._C.aa_grad_to_verts(True):
+                with self._C.aa_grad_to_verts(True), self._ctx():
                     grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
                                                          f[3], f[4], f[5], f[6])
             else:
-                grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
-                                                     f[3], f[4], f[5], f[6])
+                with self._ctx():
+                    grads = self._C.render_backward_cuda(f[0], *a, dL_dcolor_band, dL_ddepth_band, f[7], f[8], f[9],
+                                                         f[3], f[4], f[5], f[6])
         if reduce and self.world_size > 1:
             grads = allreduce_packed_grads(grads, group)
         return grads

@@ -268,8 +268,9 @@ int dm2_prepare_faces_backward(const dm2_prep_desc* d, const float* g_verts_ndc,
  *                        dintense(b = 0..B-1) | counts[2 o + 1] rows of 7 floats: id bits, dverts(3), dverts_color(3)];
  *                        cursors: 2 N uint32 of scratch.  Rows of one segment in no particular order.
  *   dm2_exchange_unpack  owner `rank`: recv holds, per source s, [recv_counts[2 s] face rows | recv_counts[2 s + 1] vertex rows]
- *                        (`rows` rows in all); they are summed into slice_v (ceil(P/N), 6) and slice_f (ceil(F/N), 1 + B),
- *                        which the call zero-fills first. */
+ *                        (`rows` rows in all; recv_counts is a HOST array -- the caller needed these numbers on the host for the
+ *                        all-to-all anyway); they are summed, source by source, into slice_v (ceil(P/N), 6) and slice_f
+ *                        (ceil(F/N), 1 + B), which the call zero-fills first. */
 int dm2_exchange_mark(int32_t B, int32_t P, int32_t F, int32_t N, const int32_t* faces, const void* face_scratch, size_t face_bytes,
                       uint8_t* flags, uint32_t* counts, void* stream);
 int dm2_exchange_pack(int32_t B, int32_t P, int32_t F, int32_t N, const uint8_t* flags, const uint32_t* counts, uint32_t* cursors,

@@ -337,8 +337,7 @@ def test_device_exchange_kernels_emulated_ranks(N):
             n = counts[s_][o][0] * (2 + B) + counts[s_][o][1] * 7
             chunks.append(sends[s_][off:off + n]); rc.append(counts[s_][o])
         recv = torch.cat(chunks) if chunks else torch.empty(0, device=dev)
-        rct = torch.tensor(rc, dtype=torch.int32, device=dev)
-        sv, sf = _C.exchange_unpack(recv, rct, sum(c[0] + c[1] for c in rc), o, B, P, F)
+        sv, sf = _C.exchange_unpack(recv, rc, sum(c[0] + c[1] for c in rc), o, B, P, F)
         gv.append(sv); gf.append(sf)
     gv = torch.cat(gv)[:P]; gf = torch.cat(gf)[:F]
     got = (gv[:, :3], gv[:, 3:], gf[:, 0], gf[:, 1:].t())

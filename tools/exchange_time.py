@@ -65,7 +65,7 @@ def main():
     res["  of which: dm2_exchange_mark (2 memsets + 2 kernels)"] = timed(lambda: _C.exchange_mark(op.fwd[7], args[5], B, P, 1))
     res["  of which: dm2_exchange_pack"] = timed(lambda: _C.exchange_pack(flags, cnt, tot, *leaves))
     send = _C.exchange_pack(flags, cnt, tot, *leaves)
-    res["  of which: dm2_exchange_unpack (2 memsets + 1 kernel)"] = timed(lambda: _C.exchange_unpack(send, cnt, int(cnt.sum()), 0, B, P, F))
+    res["  of which: dm2_exchange_unpack (2 memsets + 1 kernel)"] = timed(lambda: _C.exchange_unpack(send, cnt.cpu(), int(cnt.sum()), 0, B, P, F))
     span = torch.cat([x.reshape(-1) for x in leaves])
     res["dense: all_reduce of the packed leaves, one-rank group"] = timed(lambda: dist.all_reduce(span))
     print(f"cfg4, band 0 of {bands} ({op.rows} rows), touched faces {int(t.sum())} of {F}")

@@ -250,7 +250,8 @@ static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t m
     }
     // the pair pool is used when the caller appended room for every pair the plan counted (a smaller appendix is ignored)
     const bool use_pool = have_faces && pair_bound > 0 && bs.pool_cap >= pair_bound;
-    const int mode = dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs, use_pool, st);
+    const float pairs_per_entry = num_rendered > 0 ? (float)((double)pair_bound / (double)num_rendered) : 0.0f;
+    const int mode = dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs, use_pool, pairs_per_entry, st);
     if (forward_mode) *forward_mode = mode;
     DM2_HIP(hipGetLastError());
     return 0;

@@ -104,8 +104,11 @@ __device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, 
 // tile list.  `d` is read only then.  (A/B at cfg4: packing in a kernel of its own behind the plan's read-back, so that
 // it runs while the host sizes and enqueues the run step, costs more than it hides -- the binning part alone is bound by
 // its atomics, 0.08 ms, which here disappear behind the record traffic: 0.16 ms fused against 0.08 + 0.13 ms split.)
+#ifndef DM2_PRE_WAVES
+#define DM2_PRE_WAVES 1
+#endif
 template <bool PACK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DM2_PRE_WAVES)
 k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __restrict__ patch_min,
              const int32_t* __restrict__ faces, const float* __restrict__ verts_ndc,
              const float* __restrict__ verts_image, FaceState fs, dm2_render_desc d) {

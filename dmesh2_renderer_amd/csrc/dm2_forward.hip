@@ -103,9 +103,13 @@ k_render_forward(dm2_render_desc d, const uint2* __restrict__ ranges, const uint
     }
 }
 
+// Candidate pairs per list entry from which phase B2 of the dense forward goes class by class (dm2_forward_queue.hip): 17 at
+// 1080p / 1 M faces (slower with classes), 49 at 256 x 256 / 2 k and at depth complexity 60 (14-17 % faster).
+constexpr float FQ_CLASSES_FROM = 32.0f;
+
 int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                           float* out_color, float* out_depth, int32_t* out_tri_cnt, const BinningState& bs, bool use_pool,
-                          hipStream_t st) {
+                          float pairs_per_entry, hipStream_t st) {
     uint64_t* const hit_masks = bs.hit_masks; uint32_t* const hit_valid = bs.hit_valid;
     if (!(d.flags & DM2_FLAG_LEGACY_KERNELS)) {
         if (d.aa_temperature > 0.0f) {
@@ -114,7 +118,8 @@ int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const u
             const bool masks = !(d.flags & DM2_FLAG_NO_BACKWARD) && hit_masks && hit_valid;
             const bool pool = masks && use_pool && bs.pool && bs.pool_cap > 0;
             launch_render_forward_queue(d, ranges, face_list, is, out_color, out_depth, out_tri_cnt, masks ? hit_masks : nullptr,
-                                        masks ? hit_valid : nullptr, pool ? bs.pool : nullptr, pool ? bs.pool_cap : 0, bs.hit_base, st);
+                                        masks ? hit_valid : nullptr, pool ? bs.pool : nullptr, pool ? bs.pool_cap : 0, bs.hit_base,
+                                        pairs_per_entry >= FQ_CLASSES_FROM, st);
             return pool ? DM2_FWD_POOL : (masks ? DM2_FWD_MASKS : DM2_FWD_NONE);
         }
         // aa_temperature == 0: the reference applies no bbox test (forward.cu:314), every face of a tile's list meets

@@ -5,8 +5,19 @@
 // all 256 pixel rays and blends where the clamped barycentrics say "inside".  This is that per-pixel walk, written
 // so that all lanes of a wave stay in lock-step through the intersection test of a face (no per-lane `continue` /
 // `break` in front of it), which makes one more product free: a ballot per (list entry, wave) of the pixels the
-// entry blended into.  The backward (dm2_backward_point.hip) reads these 64-bit masks instead of repeating the
-// dense intersection test, which is two thirds of its time.
+// entry blended into.  The backward (dm2_backward_fast.hip, POINT) reads these 64-bit masks instead of repeating the
+// dense intersection test.
+//
+// Two-stage test.  A tile's list holds ~200 faces, a strip of 16 x 4 pixels is hit by a few of them; the exact test
+// (Moeller-Trumbore as the reference writes it, an IEEE division included: ~85 instructions) is only needed to DECIDE
+// for rays near a face.  When all rays of the tile start at one point (a camera: always, with the reference's ray
+// tensors) the barycentrics are ratios of three dot products of the ray direction with per-face vectors,
+//     u = rd . (E2 x T) / rd . (E2 x E1),   v = rd . (T x E1) / rd . (E2 x E1),        T = ro - p0,
+// staged once per chunk (one lane per face).  A wave first evaluates those (~20 instructions) against an error bound from
+// the un-cancelled magnitudes of the same sums (per face: ray directions are unit vectors); only if some ray is inside or
+// within the bound of the triangle does the wave run the reference's arithmetic (~60 instructions), which alone decides
+// and alone produces values.  Bit-identical output.  (Measured at 1080p / 1 M faces: a first version that carried the
+// magnitudes per component -- 39 instructions + 8 LDS reads per test -- gained nothing over the exact test alone.)
 #include <hip/hip_runtime.h>
 
 #include "dm2_device_math.h"
@@ -16,12 +27,18 @@
 namespace dm2 {
 
 constexpr int FP_CHUNK = 128;
+constexpr float FP_EPS = 1.0e-5f;     // relative bound of |quick dot - exact numerator| in units of the un-cancelled magnitude (a few ulp would do)
+
+// per staged face, for rays from `ro`: A = E2 x T, Bv = T x E1, Nn = E2 x E1 and the same sums with every term's magnitude
+struct __attribute__((aligned(16))) FpQuick { float A[3], ma, Bv[3], mb, Nn[3], md; };    // m*: FP_EPS x the sums' un-cancelled magnitudes for |rd_i| <= 1
 
 __global__ void __launch_bounds__(TILE_PIX)
 k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
                        int32_t* __restrict__ out_tri_cnt, uint64_t* __restrict__ hit_masks, uint32_t* __restrict__ hit_valid) {
     __shared__ FaceRec recs[FP_CHUNK];
+    __shared__ FpQuick s_quick[FP_CHUNK];
+    __shared__ float s_ro[3];
 
     const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -39,6 +56,12 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    // do all rays of the tile share their origin (pixel (0,0) of the tile is always inside the image)?
+    if (tid == 0) { s_ro[0] = ro.x; s_ro[1] = ro.y; s_ro[2] = ro.z; }
+    __syncthreads();
+    const f3 ro0 = {s_ro[0], s_ro[1], s_ro[2]};
+    const bool quick = __syncthreads_and(!inside || (ro.x == ro0.x && ro.y == ro0.y && ro.z == ro0.z &&
+                                                     fabsf(rd.x) <= 1.0001f && fabsf(rd.y) <= 1.0001f && fabsf(rd.z) <= 1.0001f)) != 0;
     bool done = !inside;
     float pT = 1.0f, T = 1.0f;
     uint32_t contributor = 0, last_contributor = 0;
@@ -47,11 +70,42 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     for (int base = 0; base < total; base += FP_CHUNK) {
         if (__syncthreads_count(done) == TILE_PIX) break;          // forward.cu:258-260 (also guards LDS reuse)
         const int n = min(FP_CHUNK, total - base);
-        if (tid < n) stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + base + tid], recs[tid]);
+        if (tid < n) {
+            stage_face(is.face_recs, (int64_t)b * d.F + face_list[range.x + base + tid], recs[tid]);
+            if (quick) {
+                const FaceRec& fc = recs[tid];
+                const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
+                const f3 T = ro0 - p0, E1 = p1 - p0, E2 = p2 - p0;
+                const f3 aT = {fabsf(T.x), fabsf(T.y), fabsf(T.z)}, aE1 = {fabsf(E1.x), fabsf(E1.y), fabsf(E1.z)}, aE2 = {fabsf(E2.x), fabsf(E2.y), fabsf(E2.z)};
+                auto crs = [](f3 a, f3 c) -> f3 { return {a.y * c.z - a.z * c.y, a.z * c.x - a.x * c.z, a.x * c.y - a.y * c.x}; };
+                auto crs_abs = [](f3 a, f3 c) -> f3 { return {a.y * c.z + a.z * c.y, a.z * c.x + a.x * c.z, a.x * c.y + a.y * c.x}; };
+                const f3 A = crs(E2, T), Bv = crs(T, E1), Nn = crs(E2, E1);
+                const f3 Aa = crs_abs(aE2, aT), Ba = crs_abs(aT, aE1), Na = crs_abs(aE2, aE1);
+                FpQuick& q = s_quick[tid];
+                q.A[0] = A.x; q.A[1] = A.y; q.A[2] = A.z; q.Bv[0] = Bv.x; q.Bv[1] = Bv.y; q.Bv[2] = Bv.z; q.Nn[0] = Nn.x; q.Nn[1] = Nn.y; q.Nn[2] = Nn.z;
+                q.ma = FP_EPS * 1.0001f * (Aa.x + Aa.y + Aa.z); q.mb = FP_EPS * 1.0001f * (Ba.x + Ba.y + Ba.z); q.md = FP_EPS * 1.0001f * (Na.x + Na.y + Na.z);
+            }
+        }
         __syncthreads();
 
         for (int j = 0; j < n; j++) {
             contributor++;
+            if (quick) {
+                // numerators and denominator of (u, v) up to rounding, and how far the reference's own evaluation can be from them
+                const FpQuick& q = s_quick[j];
+                const float na = __builtin_fmaf(rd.x, q.A[0], __builtin_fmaf(rd.y, q.A[1], rd.z * q.A[2]));
+                const float nb = __builtin_fmaf(rd.x, q.Bv[0], __builtin_fmaf(rd.y, q.Bv[1], rd.z * q.Bv[2]));
+                const float dn = __builtin_fmaf(rd.x, q.Nn[0], __builtin_fmaf(rd.y, q.Nn[1], rd.z * q.Nn[2]));
+                const float ma = q.ma, mb = q.mb, md = q.md;
+                // certainly outside: u < 0 or v < 0 or u + v > 1 by more than the bound, for the sign of the denominator at hand
+                const float sg = dn < 0.0f ? -1.0f : 1.0f;
+                const float a = sg * na, c = sg * nb, dd = fabsf(dn);
+                const bool out = (dd > md) && ((a < -ma) || (c < -mb) || (a + c - dd > ma + mb + md));
+                if (__ballot(!done && !out) == 0ull) {                  // (wave-uniform) nobody near this face
+                    if (lane == 0) hit_masks[((int64_t)range.x + base + j) * 4 + wid] = 0ull;
+                    continue;
+                }
+            }
             const FaceRec& fc = recs[j];
             const f3 p0 = {fc.v[0], fc.v[1], fc.v[2]}, p1 = {fc.v[3], fc.v[4], fc.v[5]}, p2 = {fc.v[6], fc.v[7], fc.v[8]};
             f3 tuv = {0, 0, 0};

@@ -52,13 +52,19 @@ static_assert(FQ_CHUNK <= 64, "one mask bit per staged face; the id window is on
 constexpr int FQ_REC_CHUNKS = (int)(sizeof(FaceRec) / 16);
 static_assert(FQ_PAIRCAP >= TILE_PIX && FQ_SURVCAP >= TILE_PIX, "a single face may own 256 pairs");
 static_assert(FQ_PAIRCAP < 65536, "16-bit slots");
-static_assert(FQ_SURVCAP <= 2 * TILE_PIX, "phase B2 runs at most two rounds");
+static_assert(FQ_SURVCAP == 2 * TILE_PIX && FQ_SURVCAP % 64 == 0 && FQ_QCAP <= 256, "one blend bit per survivor record; 8 bits of record index per queue entry");
 
 constexpr uint32_t QF_REC = 1u;      // AA overlap found (the reference takes an AA record here)
 constexpr uint32_t QF_BLEND = 2u;    // the face blends into the pixel
 
 struct __attribute__((aligned(8))) FqPair { float alpha, c0, c1, c2, depth; uint32_t flags; };
 
+// CLASSES: phase B2 takes the survivors class by class -- the ones that need the polygon clip first, the fully covered ones
+// (aa.h:493-496: area = pixel area) behind them -- so that whole waves skip the clipper.  Pays with triangles of many pixels
+// (256 x 256 / 2 k faces: forward -14 %, with depth complexity 60: -17 %), costs 4 % with the 2.5-pixel triangles of the
+// 1080p / 1 M workload (a fifth of whose survivors are fully covered: one wave in eight): the launcher picks by the plan's
+// candidate pairs per list entry.
+template <bool CLASSES>
 __global__ void __launch_bounds__(TILE_PIX, DM2_FQ_BLOCKS)
 k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, const uint32_t* __restrict__ face_list,
                        ImageState is, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -78,7 +84,10 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ uint32_t s_queue[4 * FQ_QCAP];            // survivors: q | face << 8 | corner mask << 14
     __shared__ unsigned long long s_mask[TILE_PIX];      // per pixel: faces of the chunk that left a record for it
     __shared__ __attribute__((aligned(16))) unsigned long long s_bmask[FQ_CHUNK * 4]; // per (face, wave of the tile): the pixels the face blends into
-    __shared__ __attribute__((aligned(16))) uint32_t s_rcnt[8];  // [round][wave]: blending survivors of that wave's lanes in that B2 round
+    __shared__ int s_wtotc[4];                           // survivors per wave that need the polygon clip (the others are fully covered)
+    __shared__ __attribute__((aligned(16))) uint32_t s_rcnt[8];  // (without classes) [round][wave]: blending survivors of that wave's lanes in that B2 round
+    __shared__ unsigned long long s_blend[FQ_SURVCAP / 64];  // one bit per survivor record: it blends
+    __shared__ int s_bpre[4][FQ_SURVCAP / 64];           // [wave]: set bits of s_blend in front of each word (every wave scans for itself)
     __shared__ uint32_t s_cbase;                         // pair pool: first slot of this chunk
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
@@ -158,6 +167,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             s_rect[tid] = rect;
         }
         if (tid < FQ_CHUNK * 4) s_bmask[tid] = 0;
+        if (tid < FQ_SURVCAP / 64) s_blend[tid] = 0;
         STAMP(2)
         if (wid == 0) {                                             // a chunk is at most 64 faces: all staging lanes are in wave 0
             const int inc = wave_inclusive_scan(cnt);
@@ -179,10 +189,14 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
         // ---- phase B1: classify, compact survivors in pair order ---------------------------
         const int Q = (((tot + 3) >> 2) + 63) & ~63;               // pairs per wave, whole rounds of 64
-        int wcount = 0;
+        // Survivors are compacted in pair order (their record index) but QUEUED by class: the ones that need the polygon clip
+        // from the front of the wave's queue region, the fully covered ones (all four pixel corners inside the three half
+        // planes, aa.h:493-496: area = pixel area, no clip) from its back -- phase B2 then runs whole waves of one class and the
+        // waves of the second class skip the clipper altogether.  An entry carries its record index within the wave.
+        int wcount = 0, wfull = 0;
         for (int r = 0; r < Q; r += 64) {
             const int k = wid * Q + r + lane;
-            bool surv = false;
+            bool surv = false, full = false;
             uint32_t entry = 0;
             if (k < tot) {
                 const int j = find_face(s_off, n, k);
@@ -195,19 +209,30 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     // (the rectangle already is the exact set of pixels that pass the bbox test, aa.h:96-101)
                     surv = classify_pixel(recs[j].aa, pxmin, pxmin + 1, pymin, pymin + 1, cmask);
                 }
+                full = surv && (cmask == 0xFu);
                 entry = (uint32_t)(qy * TILE + qx) | ((uint32_t)j << 8) | (cmask << 14);
             }
             const unsigned long long bal = __ballot(surv);
             const int before = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             if (k < tot) s_slot[k] = (uint16_t)before;
-            if (surv) s_queue[wid * FQ_QCAP + before] = entry;
+            if (CLASSES) {
+                const unsigned long long balf = __ballot(full), balc = bal & ~balf;
+                const int rf = wfull + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(balf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balf, 0u));
+                const int rc = (wcount - wfull) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(balc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balc, 0u));
+                if (surv) s_queue[wid * FQ_QCAP + (full ? FQ_QCAP - 1 - rf : rc)] = entry | ((uint32_t)before << 18);
+                wfull += __popcll(balf);
+            } else if (surv) s_queue[wid * FQ_QCAP + before] = entry;
             wcount += __popcll(bal);
         }
-        if (lane == 0) s_wtot[wid] = wcount;
+        if (lane == 0) { s_wtot[wid] = wcount; if (CLASSES) s_wtotc[wid] = wcount - wfull; }
         __syncthreads();
         STAMP(4)
         const int wb1 = s_wtot[0], wb2 = wb1 + s_wtot[1], wb3 = wb2 + s_wtot[2];
         int S = wb3 + s_wtot[3];
+        const int ST0 = S;                                          // queue entries of the chunk (cut 2 below may retire the last faces' records)
+        int wc1 = 0, wc2 = 0, wc3 = 0, SC = 0;                      // clip class: prefix over the waves
+        if (CLASSES) { wc1 = s_wtotc[0]; wc2 = wc1 + s_wtotc[1]; wc3 = wc2 + s_wtotc[2]; SC = wc3 + s_wtotc[3]; }
+        const int wf1 = wb1 - wc1, wf2 = wb2 - wc2, wf3 = wb3 - wc3;                                          // fully covered class
         // global survivor prefix at pair k (k <= tot)
         auto surv_before = [&](int k) -> int {
             if (k >= tot) return S;
@@ -239,24 +264,39 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         if (pool && tid == 0) cbase = atomicAdd(hit_valid + 1, (uint32_t)S);
 #endif
         // ---- phase B2: one survivor per lane ------------------------------------------------
-        // (at most two rounds of 256 survivors: SURVCAP.  Pool: a blending survivor's slot is the chunk's first slot + its rank
-        // among the chunk's blending survivors -- survivor order is (entry, pixel) order, the order of the masks -- taken with a
-        // ballot per wave and round and completed behind the barrier)
-        float pool_ratio[2] = {0.f, 0.f};
-        int pool_rank[2] = {-1, -1};
-        if (pool && lane == 0) s_rcnt[4 + wid] = 0;   // (a second round that does not run; the barrier behind B1 separates this from the last chunk's readers)
+        // Pool: a blending survivor's slot is the chunk's first slot + its rank among the chunk's blending survivors -- record
+        // order is (entry, pixel) order, the order of the masks.  Without classes the lanes run in record order: a ballot per
+        // wave and round, completed behind the barrier; with classes: one bit per record, summed behind the barrier.
+        constexpr int FQ_ROUNDS = CLASSES ? (FQ_PAIRCAP + TILE_PIX - 1) / TILE_PIX : FQ_SURVCAP / TILE_PIX;   // (queue entries <= pairs of the chunk)
+        const int ST = CLASSES ? ST0 : S;
+        float pool_ratio[FQ_ROUNDS];
+        int pool_s[FQ_ROUNDS];                                      // CLASSES: the record; else its rank among the wave's blending lanes of the round
 #pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int s = tid + rnd * TILE_PIX;
-            if (rnd == 1 && S <= TILE_PIX) break;                   // (block-uniform)
+        for (int rnd = 0; rnd < FQ_ROUNDS; rnd++) { pool_ratio[rnd] = 0.f; pool_s[rnd] = -1; }
+        if (!CLASSES && pool && lane == 0) s_rcnt[4 + wid] = 0;    // (a second round that does not run; the barrier behind B1 separates this from the last chunk's readers)
+#pragma unroll
+        for (int rnd = 0; rnd < FQ_ROUNDS; rnd++) {
+            if (rnd * TILE_PIX >= ST) break;                        // (block-uniform)
+            const int t = tid + rnd * TILE_PIX;
+            uint32_t entry = 0u;
+            int s = t;
+            if (CLASSES) {
+                // queue position t: first the clip class of all four waves, then the fully covered class
+                const bool isc = t < SC;
+                const int tc = isc ? t : t - SC;
+                const int b1 = isc ? wc1 : wf1, b2 = isc ? wc2 : wf2, b3 = isc ? wc3 : wf3;
+                const int w = (tc >= b1) + (tc >= b2) + (tc >= b3);
+                const int within = tc - (w == 0 ? 0 : (w == 1 ? b1 : (w == 2 ? b2 : b3)));
+                if (t < ST) entry = s_queue[w * FQ_QCAP + (isc ? within : FQ_QCAP - 1 - within)];
+                s = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3))) + (int)((entry >> 18) & 255u);      // the survivor's record
+            } else if (t < ST) {
+                const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
+                entry = s_queue[w * FQ_QCAP + (s - (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3))))];
+            }
             bool blend_s = false;
-            float ratio_s = 0.f;
-            if (s < S) {
-            const int w = (s >= wb1) + (s >= wb2) + (s >= wb3);
-            const int wb = (w == 0 ? 0 : (w == 1 ? wb1 : (w == 2 ? wb2 : wb3)));
-            const uint32_t entry = s_queue[w * FQ_QCAP + (s - wb)];
+            if (t < ST && s < S) {
             const int q = (int)(entry & 255u), j = (int)((entry >> 8) & 63u);
-            const uint32_t cmask = entry >> 14;
+            const uint32_t cmask = (entry >> 14) & 15u;
             const FaceRec& fc = recs[j];
             const float pxmin = (float)(uint32_t)(X0a + (q & 15)), pxmax = pxmin + 1;
             const float pymin = (float)(uint32_t)(Y0a + (q >> 4)), pymax = pymin + 1;
@@ -287,7 +327,8 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                         out.depth = i0 * fc.dep[0] + i1 * fc.dep[1] + i2 * fc.dep[2];
                         out.alpha = fc.opacity * ratio;
                         out.flags |= QF_BLEND;
-                        blend_s = true; ratio_s = ratio;
+                        pool_ratio[rnd] = ratio; blend_s = true;
+                        if (CLASSES) { pool_s[rnd] = s; if (pool) atomicOr(&s_blend[s >> 6], 1ull << (s & 63)); }
                     }
                 }
             }
@@ -297,10 +338,9 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 if (hit_masks && (out.flags & QF_BLEND)) atomicOr(&s_bmask[j * 4 + (q >> 6)], 1ull << (q & 63));
             }
             }
-            if (pool) {                                                 // (block-uniform; every lane of the wave is here)
+            if (!CLASSES && pool) {                                     // (block-uniform; every lane of the wave is here)
                 const unsigned long long bal = __ballot(blend_s);
-                pool_ratio[rnd] = ratio_s;
-                pool_rank[rnd] = blend_s ? (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) : -1;
+                pool_s[rnd] = blend_s ? (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) : -1;
                 if (lane == 0) s_rcnt[rnd * 4 + wid] = __popcll(bal);
             }
         }
@@ -326,13 +366,30 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 const int ex = wave_inclusive_scan(cj) - cj;
                 if (lane < n) hit_base[(int64_t)range.x + base + lane] = cb + (uint32_t)ex;
             }
-            const uint4 c03 = reinterpret_cast<const uint4*>(s_rcnt)[0], c47 = reinterpret_cast<const uint4*>(s_rcnt)[1];
-            const uint32_t r0 = (wid > 0 ? c03.x : 0u) + (wid > 1 ? c03.y : 0u) + (wid > 2 ? c03.z : 0u);
-            const uint32_t r1 = c03.x + c03.y + c03.z + c03.w + (wid > 0 ? c47.x : 0u) + (wid > 1 ? c47.y : 0u) + (wid > 2 ? c47.z : 0u);
-#if !defined(DM2_FQ_POOL_EXP) || DM2_FQ_POOL_EXP != 2     // (2: timing experiment only, no pool stores)
-            if (pool_rank[0] >= 0) { const uint32_t slot = cb + r0 + (uint32_t)pool_rank[0]; if (slot < pool_cap) pool[slot] = pool_ratio[0]; }
-            if (pool_rank[1] >= 0) { const uint32_t slot = cb + r1 + (uint32_t)pool_rank[1]; if (slot < pool_cap) pool[slot] = pool_ratio[1]; }
-#endif
+            if (!CLASSES) {
+                const uint4 c03 = reinterpret_cast<const uint4*>(s_rcnt)[0], c47 = reinterpret_cast<const uint4*>(s_rcnt)[1];
+                const uint32_t r0 = (wid > 0 ? c03.x : 0u) + (wid > 1 ? c03.y : 0u) + (wid > 2 ? c03.z : 0u);
+                const uint32_t r1 = c03.x + c03.y + c03.z + c03.w + (wid > 0 ? c47.x : 0u) + (wid > 1 ? c47.y : 0u) + (wid > 2 ? c47.z : 0u);
+                if (pool_s[0] >= 0) { const uint32_t slot = cb + r0 + (uint32_t)pool_s[0]; if (slot < pool_cap) pool[slot] = pool_ratio[0]; }
+                if (FQ_ROUNDS > 1 && pool_s[FQ_ROUNDS > 1 ? 1 : 0] >= 0) { const uint32_t slot = cb + r1 + (uint32_t)pool_s[1]; if (slot < pool_cap) pool[slot] = pool_ratio[1]; }
+            } else {
+            // a blending survivor's slot: the chunk's first slot + the blending records in front of its own (record order is
+            // (entry, pixel) order, the order of the masks): the bits of s_blend below it.  Every wave sums the words for itself.
+            {
+                const int c = lane < FQ_SURVCAP / 64 ? __popcll(s_blend[lane < FQ_SURVCAP / 64 ? lane : 0]) : 0;
+                const int ex = wave_inclusive_scan(c) - c;
+                if (lane < FQ_SURVCAP / 64) s_bpre[wid][lane] = ex;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (the lanes of the wave talk through s_bpre with no barrier in between)
+            }
+#pragma unroll
+            for (int rnd = 0; rnd < FQ_ROUNDS; rnd++) {
+                const int s = pool_s[rnd];
+                if (s >= 0) {
+                    const uint32_t slot = cb + (uint32_t)(s_bpre[wid][s >> 6] + __popcll(s_blend[s >> 6] & ((1ull << (s & 63)) - 1ull)));
+                    if (slot < pool_cap) pool[slot] = pool_ratio[rnd];
+                }
+            }
+            }
         }
 
         // ---- phase C: ordered blend of this pixel's records ---------------------------------
@@ -373,13 +430,18 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     STAMP_FLUSH
 }
 
+// classes: take the survivors class by class (triangles of many pixels; the caller decides from the plan's numbers)
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
-                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, hipStream_t st) {
+                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, bool classes, hipStream_t st) {
     const uint32_t Tn = (uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B);
     StageTimer tm(ST_FWD, st);
-    hipLaunchKernelGGL(k_render_forward_queue, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth, out_tri_cnt,
-                       hit_masks, hit_valid, pool, (uint32_t)pool_cap, hit_base STAMP_ARG(0));
+    if (classes)
+        hipLaunchKernelGGL(k_render_forward_queue<true>, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth,
+                           out_tri_cnt, hit_masks, hit_valid, pool, (uint32_t)pool_cap, hit_base STAMP_ARG(0));
+    else
+        hipLaunchKernelGGL(k_render_forward_queue<false>, dim3(tile_grid_blocks(Tn)), dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth,
+                           out_tri_cnt, hit_masks, hit_valid, pool, (uint32_t)pool_cap, hit_base STAMP_ARG(0));
 }
 
 }  // namespace dm2

@@ -169,15 +169,16 @@ void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, 
                                  uint32_t* hit_valid, hipStream_t st);
 // use_pool: also fill the pair pool of `bs` (the caller has checked its capacity against the plan's pair bound).
 // Returns what it left for the backward (DM2_FWD_*).
+// pairs_per_entry: the plan's pair bound / num_rendered (picks the forward's work distribution)
 int launch_render_forward(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                           float* out_color, float* out_depth, int32_t* out_tri_cnt, const BinningState& bs, bool use_pool,
-                          hipStream_t st);
+                          float pairs_per_entry, hipStream_t st);
 void launch_prepare_faces(const dm2_prep_desc& d, hipStream_t st);
 void launch_prepare_faces_backward(const dm2_prep_desc& d, const float* g_ndc, const float* g_image, const float* g_aa,
                                    float* image_grad_scratch, float* g_verts, hipStream_t st);
 void launch_render_forward_queue(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
-                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, hipStream_t st);
+                                 uint32_t* hit_valid, float* pool, int64_t pool_cap, uint32_t* hit_base, bool classes, hipStream_t st);
 void launch_render_backward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                   const float* dL_dcolor, const float* dL_ddepth, float* dL_dverts, float* dL_dverts_color,
                                   float* dL_dfaces_opacity, float* dL_dverts_ndc, float* dL_dfaces_intense,

@@ -2,6 +2,7 @@
 """profiles/<tag>_traffic.json from the per-kernel PMC summaries tools/profile_run.sh leaves
 (<tag>_cfg4_hbm_traffic.txt, <tag>_cfg4_sq_counters.txt).  usage: make_traffic_json.py <dir> <tag> > out.json"""
 import json
+import os
 import re
 import sys
 
@@ -23,8 +24,12 @@ def parse(path):
 
 hbm = parse(f"{d}/{tag}_cfg4_hbm_traffic.txt")
 sq = parse(f"{d}/{tag}_cfg4_sq_counters.txt")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_digest: the counters belong to these very sources)
+
 res = {
     "config": "cfg4",
+    "csrc_sha16": bench.csrc_digest(),
     "source": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_* in separate passes of `python3 bench.py --steps 3 --warmup 1 "
               f"--no-cpu` (tools/profile_run.sh); means per launch; profiles/{tag}_cfg4_hbm_traffic.txt, {tag}_cfg4_sq_counters.txt",
     "note_units": "FETCH_SIZE / WRITE_SIZE are reported in KiB.  gfx950 tallies a 128-B read request as 64 B for wide coalesced reads "

@@ -4,7 +4,7 @@
 #   FETCH_SIZE, WRITE_SIZE, two sets of SQ_* counters; the same for LayeredRenderer.generate at cfg3.
 # usage: bash tools/profile_run.sh <outdir under gpurun_out> <tag>
 set -u
-OUT=${1:-gpurun_out/prof}; TAG=${2:-r02}
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 20 --warmup 5 --no-cpu"

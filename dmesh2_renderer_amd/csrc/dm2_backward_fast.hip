@@ -78,7 +78,6 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ float s_pixc[6][TILE_PIX];                      // per pixel, read by phase C only: dL/dcolour, dL/ddepth, final T, T in front of the last contributor
     __shared__ float* s_fl_base[32];                           // flush, per component: destination of id 0 ...
     __shared__ int s_fl_sel[32];                               // ... which id of the record (face_id, vid[0..2]) | dwords per id << 2
-    __shared__ uint32_t s_max_lc;
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     uint32_t tile;
@@ -97,6 +96,25 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const uint32_t pmx = (uint32_t)d.patch_min[2 * b], pmy = (uint32_t)d.patch_min[2 * b + 1];
     const int X0a = X0 + (int)pmx, Y0a = Y0 + (int)pmy;
     const bool corrected = (d.flags & DM2_FLAG_CORRECTED_DV) != 0;
+
+    uint2 range = ranges[tile];                                    // block-uniform: keep it in scalar registers
+    range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
+    // entries behind every pixel's last contributor are dead: the forward left the tile's largest n_contrib (no block-wide
+    // maximum here, and the walk's first fetch leaves at once)
+    const int total = (int)min((uint32_t)__builtin_amdgcn_readfirstlane(is.tile_max_lc[tile]), range.y - range.x);
+    const uint4* const grecs = is.face_recs + (int64_t)b * d.F * FACE_REC_U4;
+    // ---- the walk's position k (0 = the tile's deepest live entry) maps to list entry range.x + total - 1 - k
+    // (backward.cu:171).  The next chunk's inputs go straight from global memory into the other LDS buffer
+    // (global_load_lds: per-lane source address, destination = wave-uniform base + lane * size; no registers held).
+    auto walk_entry = [&](int k) -> int64_t { return (int64_t)range.x + (uint32_t)(total - 1 - k); };
+    const int rl = lane / REC_CHUNKS, rp = lane - rl * REC_CHUNKS;   // record copy: 5 records x 12 parts per wave instruction
+    const int rsrc = recb_src_part(rp);
+    // request the id window [nb, nb + 64) of the walk into s_ids2[buf]
+    auto request_ids = [&](int buf, int nb) {
+        if (wid == 2 && nb + lane < total)
+            glds4(face_list + walk_entry(nb + lane), &s_ids2[buf][0]);
+    };
+    if (total > 0) request_ids(0, 0);                              // (lands while the pixels' own data is fetched)
 
     uint32_t last_contributor = 0;
     float T = 0.f;                                                 // starts as the T in front of the pixel's last contributor
@@ -118,37 +136,17 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     s_pixc[4][tid] = T_final; s_pixc[5][tid] = prev_T_final;
     T = prev_T_final;
     }
-    uint2 range = ranges[tile];                                    // block-uniform: keep it in scalar registers
-    range.x = __builtin_amdgcn_readfirstlane(range.x); range.y = __builtin_amdgcn_readfirstlane(range.y);
-
-    if (tid == 0) s_max_lc = 0;
     if (tid < M_N) fill_flush_table(tid, b, d.P, d.F, dL_dverts, dL_dverts_color, dL_dfaces_opacity, dL_dverts_ndc, dL_dfaces_intense,
                                     dL_daa_face_verts, s_fl_base, s_fl_sel, (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) != 0);
-    __syncthreads();
-    if (last_contributor) atomicMax(&s_max_lc, last_contributor);
-    __syncthreads();
-    const int total = (int)min((uint32_t)__builtin_amdgcn_readfirstlane(s_max_lc), range.y - range.x);   // entries behind every pixel's last contributor are dead
 
     const float temp = d.aa_temperature;                           // > 0 (the launcher dispatches on it)
     const float pix_area = 1.0f;
     const float bg0 = d.background[0], bg1 = d.background[1], bg2 = d.background[2];
-    const uint4* const grecs = is.face_recs + (int64_t)b * d.F * FACE_REC_U4;
 
     bool T_first_pass = true;
     float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_recd = 0.f;
     float last_alpha = 0.f, last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_depth = 0.f;
 
-    // ---- the walk's position k (0 = the tile's deepest live entry) maps to list entry range.x + total - 1 - k
-    // (backward.cu:171).  The next chunk's inputs go straight from global memory into the other LDS buffer
-    // (global_load_lds: per-lane source address, destination = wave-uniform base + lane * size; no registers held).
-    auto walk_entry = [&](int k) -> int64_t { return (int64_t)range.x + (uint32_t)(total - 1 - k); };
-    const int rl = lane / REC_CHUNKS, rp = lane - rl * REC_CHUNKS;   // record copy: 5 records x 12 parts per wave instruction
-    const int rsrc = recb_src_part(rp);
-    // request the id window [nb, nb + 64) of the walk into s_ids2[buf]
-    auto request_ids = [&](int buf, int nb) {
-        if (wid == 2 && nb + lane < total)
-            glds4(face_list + walk_entry(nb + lane), &s_ids2[buf][0]);
-    };
     // request masks + records of the chunk starting at walk position nb into buffer buf; ids[i]: face id of position nb + i
     auto request_chunk = [&](int buf, int nb, const uint32_t* ids) {
         const int nc2 = min(BM_CAND, total - nb);
@@ -165,7 +163,6 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
     };
     if (total > 0) {                                               // first chunk: synchronously
-        request_ids(0, 0);
         lds_prefetch_wait();
         __syncthreads();
         request_chunk(0, 0, s_ids2[0]);

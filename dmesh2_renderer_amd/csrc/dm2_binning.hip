@@ -201,7 +201,7 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
     if (PACK && touched != 0) {
         FaceRec r;
-        pack_face(d, b, f, r);
+        pack_face(d, b, f, i1, r);
         r.pad[0] = 0.f;
         const uint4* src = reinterpret_cast<const uint4*>(&r);
         uint4* dst = fs.recs + idx * FACE_REC_U4;
@@ -227,11 +227,10 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     __shared__ uint32_t s_c[ROUND + ROUND / 32];          // (+1 dword per 32: the runs of the 64 lanes start in different banks)
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
-    __shared__ unsigned long long s_pairs;
+    __shared__ unsigned long long s_pairs, s_total64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { s_max = 0; s_pairs = 0ull; }
+    if (tid == 0) { s_max = 0; s_pairs = 0ull; s_total64 = 0ull; }
     uint32_t carry = 0, mx = 0;
-    unsigned long long carry64 = 0;                       // the list positions are 32-bit (as the reference's int num_rendered): notice a wrap
     for (int64_t base = 0; base < Tn; base += ROUND) {
 #pragma unroll
         for (int k = 0; k < RUN; k++) {
@@ -251,7 +250,14 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
         uint32_t run = carry + before + inc - sum;
 #pragma unroll
         for (int k = 0; k < RUN; k++) { const int i = tid * RUN + k; s_c[i + (i >> 5)] = run; run += c8[k]; }
-        carry += total; carry64 += total;
+        carry += total;
+        // (the pair count in 64 bits, on its own path: a round's 32-bit total may itself have wrapped)
+        unsigned long long s64 = 0;
+#pragma unroll
+        for (int k = 0; k < RUN; k++) s64 += c8[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s64 += __shfl_xor(s64, o);
+        if (lane == 0 && s64) atomicAdd(&s_total64, s64);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RUN; k++) {
@@ -274,7 +280,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t longest = carry64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max;      // (per-round totals stay below 2^32: 8192 tiles)
+        const uint32_t longest = s_total64 > 0x7FFFFFFFull ? 0xFFFFFFFFu : s_max;     // the list positions are 32-bit (as the reference's int num_rendered): notice a wrap
         const unsigned long long pairs = s_pairs;
         meta[0] = carry; meta[1] = longest; meta[2] = (uint32_t)pairs; meta[3] = (uint32_t)(pairs >> 32);
         if (host_meta) {

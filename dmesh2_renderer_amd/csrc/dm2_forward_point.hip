@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dm2_device_math.h"
+#include "dm2_pairs.h"
 #include "dm2_stage.h"
 #include "dm2_state.h"
 
@@ -136,6 +137,14 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
     }
 
+    // the tile's largest n_contrib: where the backward's walk starts (dm2_backward_fast.hip)
+    __shared__ uint32_t s_maxlc;
+    __syncthreads();
+    if (tid == 0) s_maxlc = 0;
+    __syncthreads();
+    { const uint32_t m = wave_inclusive_max(last_contributor); if (lane == 63 && m) atomicMax(&s_maxlc, m); }
+    __syncthreads();
+    if (tid == 0) is.tile_max_lc[tile] = s_maxlc;
     if (inside) {
         is.final_prev_T[pix] = pT;
         is.final_T[pix] = T;

@@ -89,6 +89,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ unsigned long long s_blend[FQ_SURVCAP / 64];  // one bit per survivor record: it blends
     __shared__ int s_bpre[4][FQ_SURVCAP / 64];           // [wave]: set bits of s_blend in front of each word (every wave scans for itself)
     __shared__ uint32_t s_cbase;                         // pair pool: first slot of this chunk
+    __shared__ uint32_t s_maxlc;
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     uint32_t tile;
@@ -416,6 +417,12 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         STAMP(6)
     }
 
+    // the tile's largest n_contrib: where the backward's walk starts (dm2_backward_fast.hip)
+    if (tid == 0) s_maxlc = 0;
+    __syncthreads();
+    { const uint32_t m = wave_inclusive_max(last_contributor); if (lane == 63 && m) atomicMax(&s_maxlc, m); }
+    __syncthreads();
+    if (tid == 0) is.tile_max_lc[tile] = s_maxlc;
     if (inside) {
         is.final_prev_T[pix] = pT;
         is.final_T[pix] = T;

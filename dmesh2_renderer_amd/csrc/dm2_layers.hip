@@ -203,6 +203,15 @@ k_pack_tets(dm2_layers_desc d, TetRec* __restrict__ out) {
     for (int i = 0; i < 4; i++) {
         const int tf = d.tet_faces[4 * t + i];
         TetFaceRec& fr = r.f[i];
+        if ((unsigned)tf >= (unsigned)d.F) {
+            // a padded or invalid entry of a tet the walk may never reach (the reference only touches tets a ray enters): no face
+            // here -- the walk's "current face among the tet's four" test fails as the reference's cnt != 3 would
+            fr.face_id = -1; fr.next_tet = -1;
+#pragma unroll
+            for (int c = 0; c < 9; c++) fr.v[c] = 0.f;
+            fr.n[0] = fr.n[1] = fr.n[2] = 0.f;
+            continue;
+        }
         fr.face_id = tf;
 #pragma unroll
         for (int c = 0; c < 3; c++) {

@@ -32,6 +32,9 @@ static_assert(sizeof(FaceRec) == 236 + 4 * DM2_FACEREC_PAD && sizeof(FaceRec) % 
 // The default backward's shorter LDS record: of the AA tables only corners, edges, reciprocals and the edge flags (parts 0-4
 // of the global record; the normals, their offsets and the bbox serve the forward's classification only), then world
 // corners ... vertex ids (parts 8-14): 12 of the 16 sixteen-byte parts, 192 bytes.
+#ifndef DM2_FACERECB_PAD
+#define DM2_FACERECB_PAD 0
+#endif
 struct __attribute__((aligned(16))) FaceRecB {
     float v2[6], e[6], r[6];   // aa_face_verts / edges / recip  (named v2: `v` are the world-space corners below)
     uint32_t zmask;
@@ -43,11 +46,15 @@ struct __attribute__((aligned(16))) FaceRecB {
     int face_id;
     int vid[3];
     float pad;
+#if DM2_FACERECB_PAD
+    float pad2[4];      // 208-B stride (52 dwords = 20 mod 32 banks): the same field of eight consecutive records lies in eight different
+                        // banks (192 B = 16 mod 32: only two)
+#endif
 };
-static_assert(sizeof(FaceRecB) == 192, "FaceRecB layout");
-constexpr int FACE_RECB_PARTS = 12;
+static_assert(sizeof(FaceRecB) == 192 + 16 * DM2_FACERECB_PAD, "FaceRecB layout");
+constexpr int FACE_RECB_PARTS = 12 + DM2_FACERECB_PAD;       // (the pad is copied as a part of its own: LDS-direct destinations are lane-contiguous)
 // global part (16 B) of the packed record that holds part rp of a FaceRecB
-__device__ __forceinline__ int recb_src_part(int rp) { return rp < 5 ? rp : rp + 3; }
+__device__ __forceinline__ int recb_src_part(int rp) { return rp < 5 ? rp : (rp < 12 ? rp + 3 : 15); }
 // view of a FaceRecB's AA members under the names dm2_clip_fast.h uses
 struct AAFaceB { const float* v; const float* e; const float* r; uint32_t zmask; };
 
@@ -98,7 +105,8 @@ __device__ __forceinline__ void pixel_ray(const Desc& d, int b, int64_t pix, uin
 }
 
 // Gather face `face_id` of view `b` from the op's input tensors into `r` (the preprocess kernel packs with it).
-__device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int face_id, FaceRec& r) {
+// iv1: verts_image of the face's second vertex (the caller has it at hand)
+__device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int face_id, float2 iv1, FaceRec& r) {
     const int v0 = d.faces[3 * face_id], v1 = d.faces[3 * face_id + 1], v2 = d.faces[3 * face_id + 2];
     r.face_id = face_id; r.vid[0] = v0; r.vid[1] = v1; r.vid[2] = v2;
     const int vs[3] = {v0, v1, v2};
@@ -157,11 +165,9 @@ __device__ __forceinline__ void pack_face(const dm2_render_desc& d, int b, int f
         zm |= (az[2 * i + 1] ? 1u : 0u) << (2 * i + 1);
     }
     // bit 8: the CCW reorder swapped corners 1 and 2 (pyrenderer.py:8,521-529): aa corner 1 is not this face's vertex 1
-    // (DM2_FLAG_AA_GRAD_TO_VERTS routes the corner gradients back with it; bits 0..5 are the edge flags)
-    if (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) {                    // (only a forward that announces such a backward pays the gather)
-        const float2 iv1 = *reinterpret_cast<const float2*>(d.verts_image + ((int64_t)b * d.P + v1) * 2);
-        if (!(av[1].x == iv1.x && av[1].y == iv1.y)) zm |= 1u << 8;
-    }
+    // (DM2_FLAG_AA_GRAD_TO_VERTS routes the corner gradients back with it; bits 0..5 are the edge flags).  Noted by every
+    // forward, whatever its flags: a backward that asks for the routing never depends on what the forward was told.
+    if (!(av[1].x == iv1.x && av[1].y == iv1.y)) zm |= 1u << 8;
     }
     r.aa.zmask = zm;
     // aa_face_verts.min(2)/.max(2)  (forward.cu:480-481, backward.cu:589-590)

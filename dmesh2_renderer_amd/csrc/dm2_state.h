@@ -77,11 +77,12 @@ struct ImageState {
     float* final_prev_T;      // (N)
     uint32_t* n_contrib;      // (N)
     uint2* ranges;            // (Tn) [start,end) into face_list
+    uint32_t* tile_max_lc;    // (Tn) the largest n_contrib of the tile's pixels (written by the dense and the point-sampled forward)
     const uint4* face_recs;   // not part of the image scratch: FaceState::recs of the same forward, set by the host API
     static ImageState carve(void* base, int64_t N, int64_t Tn, size_t* total = nullptr) {
         Carver c(base); ImageState s; s.face_recs = nullptr;
         s.final_T = c.take<float>(N); s.final_prev_T = c.take<float>(N); s.n_contrib = c.take<uint32_t>(N);
-        s.ranges = c.take<uint2>(Tn);
+        s.ranges = c.take<uint2>(Tn); s.tile_max_lc = c.take<uint32_t>(Tn);
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }

@@ -242,3 +242,58 @@ def test_record_stack_desync_corner_size_of_the_deviation():
     lost = int((np.abs(g20["faces_opacity"] - g0["faces_opacity"]) > 1e-6 * np.abs(g0["faces_opacity"]).max()).sum())
     print(f"record-stack desync corner: reference K=20 vs K=0 gradients, rel L_inf {dev}; {lost} of 300 opacity gradients differ")
     assert max(dev.values()) > 1e-3                           # the corner is real in this scene: the documented deviation
+
+
+# ---- non-finite per-pair gradients stay inside the rows of the face that produced them ----------------------------
+def test_non_finite_gradient_of_a_sliver_face_is_contained():
+    """One face whose WORLD triangle is 1e-13 across (at the world origin, image-space tables unchanged): it blends like any
+    other face (its ray/plane denominator is tiny but not 0), and its dL/dverts chain divides by the SQUARE of that
+    denominator (auxiliary.h:262-265, no effective guard): 1 / 0 after underflow.  The reference's per-pair atomics add that
+    Inf / NaN to the face's own three vertex rows only; the backward's segmented row scans must do the same (a multiply-by-0
+    continuation mask would turn a neighbouring run's Inf into NaN in up to 15 other faces' rows)."""
+    orc = _orc()
+    args = list(_soup(64, 48, 300, 62, 1.0))
+    verts = args[4].clone()
+    f = 77
+    verts[3 * f] = torch.tensor([0.0, 0.0, 0.0]); verts[3 * f + 1] = torch.tensor([1e-13, 0.0, 0.0]); verts[3 * f + 2] = torch.tensor([0.0, 1e-13, 0.0])
+    args[4] = verts
+    rng = np.random.default_rng(6)
+    ref = orc.render_forward_cuda(*to_numpy_args(args))
+    gc = rng.standard_normal(ref.color.shape).astype(np.float32)
+    gd = rng.standard_normal(ref.depth.shape).astype(np.float32)
+    with np.errstate(all="ignore"):
+        gref = orc.render_backward_cuda(ref, gc, gd)
+    bad_ref = ~np.isfinite(gref["verts"]).all(axis=1)
+    assert bad_ref.any() and set(np.where(bad_ref)[0]) <= {3 * f, 3 * f + 1, 3 * f + 2}      # the oracle: that face's rows only
+    for flags in (0, _C().DM2_FLAG_LEGACY_KERNELS):
+        out, grads = _hip_fwd_bwd(args, gc, gd, flags, flags)
+        assert np.array_equal(out[1].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+        gv = grads[0]
+        bad = ~np.isfinite(gv).all(axis=1)
+        assert set(np.where(bad)[0]) <= {3 * f, 3 * f + 1, 3 * f + 2}, np.where(bad)[0]
+        ok = ~bad_ref & ~bad
+        assert rel_linf(gv[ok], gref["verts"][ok]) <= GRAD_TOL
+        for g, n in zip(grads[1:], GRAD_NAMES[1:]):
+            assert np.isfinite(g).all() and rel_linf(g, gref[n]) <= GRAD_TOL, n
+
+
+def test_aa_gradient_routing_does_not_depend_on_the_forwards_flags():
+    """DM2_FLAG_AA_GRAD_TO_VERTS in the backward only: the forward's packed records note the CCW reorder whatever its flags
+    were (the routing used to be silently wrong for clockwise faces when the forward had not been told)."""
+    C = _C()
+    from test_gpu_prep import mixed_orientation
+    sc = mixed_orientation(scenes.triangle_soup(64, 48, 300, scenes.SEED_BASE + 63, shared_verts=True))
+    args = capture_forward_args(sc, [0], [[0, 0]], 64, 48, 1.0, 20)[0]
+    dargs = _dev(args)
+    rng = np.random.default_rng(7)
+    gc = torch.from_numpy(rng.standard_normal((1, 48, 64, 3)).astype(np.float32)).cuda()
+    gd = torch.from_numpy(rng.standard_normal((1, 48, 64)).astype(np.float32)).cuda()
+    res = []
+    for told in (False, True):
+        with C.aa_grad_to_verts(told):
+            out = C.render_forward_cuda(*dargs)
+        with C.aa_grad_to_verts(True):
+            g = C.render_backward_cuda(out[0], *dargs, gc, gd, out[7], out[8], out[9], out[3], out[4], out[5], out[6])
+        res.append(g[5].cpu().numpy())
+    assert res[0].shape == (1, args[4].shape[0], 2) and np.abs(res[0]).max() > 0
+    assert rel_linf(res[0], res[1]) <= 1e-6

@@ -252,3 +252,21 @@ def test_layers_exact():
         assert np.array_equal(layers.cpu().numpy(), rl)
         assert (rc > 0).mean() > 0.3                     # the lattice is actually hit
         assert layers.dtype == torch.int32 and layers.shape == (2, H, W, L)
+
+
+def test_layers_with_an_unreachable_padded_tet():
+    """A tet no face points to, whose face ids are padding (-1 and beyond F): the reference's walk never reads it.  The packed
+    tet records are built for ALL tets, so their builder has to leave such entries alone: same layers, no out-of-bounds read."""
+    C = _C()
+    W, H = 96, 64
+    sc = scenes.tet_lattice(W, H, 4, seed=scenes.SEED_BASE + 5)
+    import dmesh2_renderer_amd as dm2
+    scd = sc.to("cuda")
+    lr = dm2.LayeredRenderer(scd.mv, scd.proj, W, H, "cuda")
+    base = lr.generate([0], scd.verts, scd.faces, scd.tets, scd.face_tets, scd.tet_faces, scd.faces_existence, 3)
+    F = scd.faces.shape[0]
+    tets2 = torch.cat([scd.tets, scd.tets[:2]])
+    tf2 = torch.cat([scd.tet_faces, torch.tensor([[-1, -1, -1, -1], [F + 1000, 2 ** 30, -7, F]], dtype=scd.tet_faces.dtype, device="cuda")])
+    got = lr.generate([0], scd.verts, scd.faces, tets2, scd.face_tets, tf2, scd.faces_existence, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(base[0], got[0]) and torch.equal(base[1], got[1])

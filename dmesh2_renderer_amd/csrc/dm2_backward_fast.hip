@@ -361,6 +361,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
             const FaceRecB& fcD = recs[j];
 #endif
             float dL_diu = 0.f, dL_div = 0.f, dL_doarea = 0.f;
+            ISA_MARK(D_group1)
             {   // group 1: vertex colours, NDC depth, intensity, opacity
                 float g1[14];
 #pragma unroll
@@ -411,6 +412,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     arow[M_FLAG] = 1.0f;
                 }
             }
+            ISA_MARK(D_group2)
             // group 2: AA corners.  d(area)/d(corners) without a polygon (dm2_clip_fast.h); a pair it flags as a tie adds nothing
             // here: it is queued with its dL/d(area) for the exact clipper (k_aa_ties below).  One atomic per wave with such a
             // pair, its return value looked at behind group 3.
@@ -438,6 +440,7 @@ k_render_backward_fast(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                     for (int c = 0; c < 6; c++) atomicAdd(arow + M_AA + c, g2[c]);
                 }
             }
+            ISA_MARK(D_group3)
             {   // group 3: world-space corners through the ray/triangle intersection
                 float g3[9];
 #pragma unroll

@@ -63,7 +63,9 @@ __device__ __forceinline__ void fast_edge(const Face& f, float pxmin, float pxma
     // Jacobian), V = 1/2 D.y (1, -e.x / e.y) for a crossing of a y = const line (its x = p0x + t e.x moves, weight 1/2 D.y;
     // dt/dp0y = -(1 - t) / e.y, dt/dp1y = -t / e.y: aa.h:276-294 up to the rounding of one factor), V = -1/2 D.x (-e.y / e.x, 1)
     // for a crossing of an x = const line.
-    const float kx = on ? ex * ry : 0.0f, ky = on ? ey * rx : 0.0f;
+    // (kx, ky may be infinite for an axis-parallel edge: such an edge has no crossing with the lines parallel to it, so the
+    // vectors built from them are never the ones selected below)
+    const float kx = ex * ry, ky = ey * rx;
     const float vyy = -(kx * hx), vxx = -(ky * hy);
     const float Vsx = sV ? hx : (sX ? vxx : hx), Vsy = sV ? hy : (sX ? hy : vyy);
     const float Vex = eV ? hx : (eX ? vxx : hx), Vey = eV ? hy : (eX ? hy : vyy);
@@ -81,15 +83,11 @@ __device__ __forceinline__ void fast_edge(const Face& f, float pxmin, float pxma
         const float bx = fminf(fabsf(pxmin - p1x), fabsf(pxmax - p1x)), by = fminf(fabsf(pymin - p1y), fabsf(pymax - p1y));
         tie = tie || (zx && !(fminf(ax, bx) >= FAST_TIE_ISZERO)) || (zy && !(fminf(ay, by) >= FAST_TIE_ISZERO));
     }
-    // (c) the edge's line within ~delta of a pixel corner that lies on the edge: the crossings with the two pixel lines
-    // through that corner then have (nearly) the same parameter, inside [0, 1] widened by delta / |e|
+    // (c) the edge's line within ~delta of a pixel corner: the crossings with the two pixel lines through that corner then have
+    // (nearly) the same parameter.  (Whether that corner lies on the edge at all is not looked at: one pair in a thousand more.)
     const float emax = fmaxf(fabsf(ex), fabsf(ey));
-    const float tt = delta * __builtin_amdgcn_rcpf(emax), thi = 1.0f + tt;     // (a margin: v_rcp_f32's ulp does not matter)
-    const bool cAB = !(fabsf(tA - tB) * emax >= delta) && (tA >= -tt) && (tA <= thi);
-    const bool cBC = !(fabsf(tB - tC) * emax >= delta) && (tB >= -tt) && (tB <= thi);
-    const bool cCD = !(fabsf(tC - tD) * emax >= delta) && (tC >= -tt) && (tC <= thi);
-    const bool cDA = !(fabsf(tD - tA) * emax >= delta) && (tD >= -tt) && (tD <= thi);
-    tie = tie || cAB || cBC || cCD || cDA;
+    const float m3 = fminf(fminf(fabsf(tA - tB), fabsf(tB - tC)), fminf(fabsf(tC - tD), fabsf(tD - tA)));
+    tie = tie || !(m3 * emax >= delta);
 }
 
 // g: [3][2] row-major, d(area)/d(aa_face_verts) of the pair.  tie: the pair needs the exact clipper instead (g is then

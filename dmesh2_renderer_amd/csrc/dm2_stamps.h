@@ -34,3 +34,10 @@ namespace dm2 { unsigned long long* stamps_table(); }   // device pointer to [2]
 #endif
 #define STAMP_FLUSH
 #endif
+
+// a comment line in the -save-temps ISA of a -DDM2_ISA_MARKS build (tools/isa_budget.py), nothing otherwise
+#ifdef DM2_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; DM2_MARK " #name);
+#else
+#define ISA_MARK(name)
+#endif

@@ -32,6 +32,7 @@ DM2_FLAG_NO_BACKWARD = 4
 DM2_FLAG_ANALYTIC_RAYS = 8
 DM2_FLAG_AA_GRAD_TO_VERTS = 16
 DM2_FLAG_TABLES_FROM_IMAGE = 32
+DM2_FLAG_NO_PAIR_POOL = 64
 SCRATCH_FACE, SCRATCH_IMAGE, SCRATCH_BINNING, SCRATCH_LAYER_IMAGE, SCRATCH_LAYER_TETS, SCRATCH_PAIR_POOL, SCRATCH_TIE_QUEUE = range(7)
 # what a forward left for its backward (include/dm2_hip.h DM2_FWD_*)
 FWD_UNKNOWN, FWD_NONE, FWD_MASKS, FWD_POOL, FWD_POINT = 0, 1, 2, 3, 4
@@ -420,6 +421,8 @@ def render_forward_cuda(*args):
         key = (dev.index, B, W, H, F)
         with _lock:
             hint = _bin_hint.get(key, 0)
+        if _pool_budget(N, 0) <= 0:
+            d.flags |= DM2_FLAG_NO_PAIR_POOL
         bin_buf = _bytes(dev, hint)
         rc = lib.dm2_forward(ctypes.byref(d), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf), bin_buf.numel(), _ptr(img_buf), img_buf.numel(),
                              _ptr(color), _ptr(depth), _ptr(tri_cnt), st, ctypes.byref(nr), ctypes.byref(longest), ctypes.byref(pairs),
@@ -427,10 +430,15 @@ def render_forward_cuda(*args):
         if rc not in (0, 2):
             raise _err(lib, "render_forward_cuda")
         R = int(nr.value)
-        wants_pool = d.aa_temperature > 0.0 and not (d.flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS))
-        pool = lib.dm2_scratch_bytes(SCRATCH_PAIR_POOL, int(pairs.value), 0) if wants_pool and int(pairs.value) <= _pool_budget(N, R) else 0
+        wants_pool = d.aa_temperature > 0.0 and not (d.flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS | DM2_FLAG_NO_PAIR_POOL))
+        over = wants_pool and int(pairs.value) > _pool_budget(N, R)
+        pool = lib.dm2_scratch_bytes(SCRATCH_PAIR_POOL, int(pairs.value), 0) if wants_pool and not over else 0
         need = lib.dm2_scratch_bytes(SCRATCH_BINNING, R, Tn) + pool
-        if rc == 2:
+        if rc == 2 or (over and int(mode.value) == FWD_POOL):
+            # (over budget although last frame's buffer happened to have room: rendered again with masks only, so that the
+            # backward's tie scratch stays within the budget too)
+            if over:
+                d.flags |= DM2_FLAG_NO_PAIR_POOL
             bin_buf = _bytes(dev, need + need // 4)
             if lib.dm2_forward_run(ctypes.byref(d), R, int(longest.value), int(pairs.value), _ptr(face_buf), face_buf.numel(), _ptr(bin_buf),
                                    bin_buf.numel(), _ptr(img_buf), img_buf.numel(), _ptr(color), _ptr(depth), _ptr(tri_cnt), st,

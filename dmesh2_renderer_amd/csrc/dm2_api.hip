@@ -249,7 +249,7 @@ static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t m
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }
     // the pair pool is used when the caller appended room for every pair the plan counted (a smaller appendix is ignored)
-    const bool use_pool = have_faces && pair_bound > 0 && bs.pool_cap >= pair_bound;
+    const bool use_pool = have_faces && pair_bound > 0 && bs.pool_cap >= pair_bound && !(d->flags & DM2_FLAG_NO_PAIR_POOL);
     const float pairs_per_entry = num_rendered > 0 ? (float)((double)pair_bound / (double)num_rendered) : 0.0f;
     const int mode = dm2::launch_render_forward(*d, is.ranges, bs.face_list, is, out_color, out_depth, out_tri_cnt, bs, use_pool, pairs_per_entry, st);
     if (forward_mode) *forward_mode = mode;
@@ -276,7 +276,7 @@ int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
     if (N > 0 && image_scratch && dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) <= image_bytes) ranges = dm2::ImageState::carve(image_scratch, N, Tn).ranges;
     if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, ranges)) return 1;
     const bool planned = d->P != 0 && (int64_t)d->B * d->F != 0 && Tn != 0;     // (otherwise no plan kernel ran)
-    const bool wants_pool = d->aa_temperature > 0.0f && !(d->flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS));
+    const bool wants_pool = d->aa_temperature > 0.0f && !(d->flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS | DM2_FLAG_NO_PAIR_POOL));
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) + (wants_pool ? dm2_scratch_bytes(DM2_SCRATCH_PAIR_POOL, *pair_bound, 0) : 0) > binning_bytes)
         return 2;                                                                // plan done; allocate, then dm2_forward_run
     return forward_run(d, *num_rendered, *max_tile_entries, *pair_bound, face_scratch, face_bytes, binning_scratch, binning_bytes,

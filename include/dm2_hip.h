@@ -100,6 +100,9 @@ typedef struct dm2_render_desc {
                                     (SURVEY.md 8(f) rank 1): 114 B per face less to write and 114 to read.  The backward's dL/d(aa
                                     corners) then only exists per vertex: combine with DM2_FLAG_AA_GRAD_TO_VERTS. */
 
+#define DM2_FLAG_NO_PAIR_POOL 64   /* dm2_forward*: leave blend masks only (DM2_FWD_MASKS), whatever room the binning scratch has behind
+                                    its fixed part: for a caller that finds the plan's pair_bound too large for its memory budget */
+
 /* Scratch kinds for dm2_scratch_bytes (state.h:18-61). */
 enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 2 * (B*tiles) + 1 for Renderer (holds the packed face records,

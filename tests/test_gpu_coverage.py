@@ -297,3 +297,37 @@ def test_aa_gradient_routing_does_not_depend_on_the_forwards_flags():
         res.append(g[5].cpu().numpy())
     assert res[0].shape == (1, args[4].shape[0], 2) and np.abs(res[0]).max() > 0
     assert rel_linf(res[0], res[1]) <= 1e-6
+
+
+# ---- every route from a forward to its backward kernel -----------------------------------------------------------
+@pytest.mark.parametrize("route", ["pool", "masks_only", "unknown_with_pool", "unknown_masks_only", "told_wrong_object"])
+def test_backward_kernel_selection(route):
+    """The backward's kernel follows what the forward left (include/dm2_hip.h DM2_FWD_*): masks + pair pool -> the polygon-free
+    kernel + tie pass; masks only (the caller gave the pool no room) -> the exact-clipper mask kernel; not told -> every
+    candidate is launched and looks at the device-side word itself.  Same gradients on every route."""
+    C, orc = _C(), _orc()
+    args = _soup(96, 64, 500, 64, 1.0)
+    dargs = _dev(args)
+    ref = orc.render_forward_cuda(*to_numpy_args(args))
+    rng = np.random.default_rng(8)
+    gc = rng.standard_normal(ref.color.shape).astype(np.float32); gd = rng.standard_normal(ref.depth.shape).astype(np.float32)
+    gref = orc.render_backward_cuda(ref, gc, gd)
+    budget = C._pool_budget
+    try:
+        if "masks_only" in route:
+            C._pool_budget = lambda N, R: 0                     # no room for the pool: DM2_FWD_MASKS
+        out = C.render_forward_cuda(*dargs)
+    finally:
+        C._pool_budget = budget
+    assert C.last_forward_mode() == (C.FWD_MASKS if "masks_only" in route else C.FWD_POOL)
+    assert np.array_equal(out[1].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+    bin_buf = out[8]
+    if route.startswith("unknown") or route == "told_wrong_object":
+        bin_buf = out[8].clone()                                # another tensor object: the shim's note of the mode is gone
+        assert not hasattr(bin_buf, "_dm2_fwd_mode")
+    tgc, tgd = torch.from_numpy(gc).cuda(), torch.from_numpy(gd).cuda()
+    g = C.render_backward_cuda(out[0], *dargs, tgc, tgd, out[7], bin_buf, out[9], out[3], out[4], out[5], out[6])
+    _check_grads([x.cpu().numpy() for x in g], gref)
+    # a second backward of the same forward (retain_graph): the tie queue's counters were left as they were found
+    g2 = C.render_backward_cuda(out[0], *dargs, tgc, tgd, out[7], bin_buf, out[9], out[3], out[4], out[5], out[6])
+    _check_grads([x.cpu().numpy() for x in g2], gref)

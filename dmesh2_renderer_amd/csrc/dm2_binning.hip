@@ -119,25 +119,30 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
     const float* ndc = verts_ndc + (int64_t)b * P * 3;
     const float* img = verts_image + (int64_t)b * P * 2;
-    const float z0 = ndc[3 * v0 + 2], z1 = ndc[3 * v1 + 2], z2 = ndc[3 * v2 + 2];
     const float2 i0 = *reinterpret_cast<const float2*>(img + 2 * v0);
     const float2 i1 = *reinterpret_cast<const float2*>(img + 2 * v1);
     const float2 i2 = *reinterpret_cast<const float2*>(img + 2 * v2);
-    float max_z = fmaxf(fmaxf(z0, z1), z2);
-    float min_z = fminf(fminf(z0, z1), z2);
-    float depth = ((0.0f + z0) + z1) + z2;
-    depth = depth / 3.0f;
 
+    // The tile rectangle first (forward.cu:77-88), the depth cull (forward.cu:71) only for faces that have one: a face has
+    // to pass both, and most (view, face) items of a window or of a rank's band fail this one -- their NDC z is never fetched.
     uint32_t touched = 0, lo = 0, hi = 0;
     float d01 = 0.f, dmin = 0.f, dmax = 0.f;
-    if (!(max_z < -1.0f || min_z > 1.0f)) {                               // forward.cu:71
+    {
         uint32_t x0, y0, x1, y1;
         patch_rect_from_tri(pmx, pmy, i0.x, i0.y, i1.x, i1.y, i2.x, i2.y, gx, gy, x0, y0, x1, y1);
         touched = (y1 - y0) * (x1 - x0);                                   // forward.cu:88,93
         if (touched != 0) {
-            auto to01 = [](float z) { float d = (z + 1.0f) * 0.5f; if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f; return d; };
-            d01 = to01(depth); dmin = to01(min_z); dmax = to01(max_z);
-            lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
+            const float z0 = ndc[3 * v0 + 2], z1 = ndc[3 * v1 + 2], z2 = ndc[3 * v2 + 2];
+            const float max_z = fmaxf(fmaxf(z0, z1), z2);
+            const float min_z = fminf(fminf(z0, z1), z2);
+            float depth = ((0.0f + z0) + z1) + z2;
+            depth = depth / 3.0f;
+            if (max_z < -1.0f || min_z > 1.0f) touched = 0;               // forward.cu:71
+            else {
+                auto to01 = [](float z) { float d = (z + 1.0f) * 0.5f; if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f; return d; };
+                d01 = to01(depth); dmin = to01(min_z); dmax = to01(max_z);
+                lo = x0 | (y0 << 16); hi = x1 | (y1 << 16);
+            }
         }
     }
     const bool small = touched != 0 && touched <= 4;

@@ -23,5 +23,10 @@ python3 tools/trim_rocprof.py $OUT/ktl > $OUT/${TAG}_layers_cfg3_kernel_stats.cs
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/lfetch -- python3 tests/layers_time.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/lwrite -- python3 tests/layers_time.py > /dev/null 2>&1
 { echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tests/layers_time.py (cfg3: 1024x1024, 93 750 tets, 191 250 faces, 4 layers); per launch means"; python3 tools/pmc_summary.py $OUT/lfetch; python3 tools/pmc_summary.py $OUT/lwrite; } > $OUT/${TAG}_layers_cfg3_hbm_traffic.txt
-rm -rf $OUT/kt $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/ktl $OUT/lfetch $OUT/lwrite
+# point-sampled coverage (aa_temperature 0) and the sharded step's local kernels (exchange, band plan)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt0 -- python3 bench.py --steps 20 --warmup 5 --no-cpu --aa-temperature 0 > $OUT/${TAG}_temp0_under_rocprof.log 2>&1
+python3 tools/trim_rocprof.py $OUT/kt0 > $OUT/${TAG}_cfg4_temp0_kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktx -- python3 tools/exchange_time.py 8 > $OUT/${TAG}_exchange_time_8.txt 2>&1
+python3 tools/trim_rocprof.py $OUT/ktx > $OUT/${TAG}_exchange_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/kt $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/ktl $OUT/lfetch $OUT/lwrite $OUT/kt0 $OUT/ktx
 ls -la $OUT

@@ -8,6 +8,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)              # drop the argument list
     name = re.sub(r"<.*", "<...>", name)           # drop template arguments
     return name[:96]

@@ -187,7 +187,7 @@ def end_to_end_ms(cfg, device, iters=10):
     return res
 
 
-def point_sampled_ms(cfg, device, steps=5):
+def point_sampled_ms(cfg, device, steps=20):
     """SURVEY.md 8(d) asks for the aa_temperature = 0 figure next to the headline one: same frame, same faces,
     point-sampled coverage (no AA), forward+backward ms per step.  Reported in `config`, never in `value`."""
     global AA_TEMPERATURE
@@ -203,7 +203,7 @@ def point_sampled_ms(cfg, device, steps=5):
         op.forward()
         op.backward(dLc, dLd)
 
-    for _ in range(2):
+    for _ in range(5):
         step()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()

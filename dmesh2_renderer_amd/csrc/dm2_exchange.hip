@@ -11,7 +11,7 @@
 //                                the host can read back while the backward still runs
 //   k_xchg_pack                  after the backward: [id | dopacity | dintense(B)] and [id | dverts(3) | dcolor(3)] rows into the
 //                                send buffer, per owner [face rows | vertex rows]; places inside a segment: one global atomic per
-//                                block of 8192 ids and owner, LDS cursors inside the block
+//                                block of 32768 ids and owner, LDS cursors inside the block
 //   k_xchg_unpack                owner: every received row is added to the dense slice, one launch per source (rows of one source
 //                                have distinct ids: plain adds, and the same summation order on every rank)
 //
@@ -25,28 +25,52 @@ namespace dm2 {
 
 constexpr int XCHG_MAX_RANKS = 64;
 
-// One count per active lane into cnt[slot] (LDS), the lanes of a wave that share a slot through ONE atomic (neighbouring ids share
-// their owner: one or two distinct slots per wave); returns the lane's place, as its own atomicAdd(.., 1) would.  Whole waves only.
-__device__ __forceinline__ uint32_t wave_slot_place(uint32_t* cnt, uint32_t slot, bool act) {
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    unsigned long long todo = __ballot(act);
-    uint32_t place = 0;
-    while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
-        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, l);
-        const unsigned long long m = __ballot(act && slot == sl);
-        uint32_t base = 0;
-        if (lane == l) base = atomicAdd(cnt + sl, (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
-        if (act && slot == sl) place = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        todo &= ~m;
+constexpr int XCHG_THREADS = 1024;
+constexpr int XCHG_IDS_PER_WAVE = 2048;                   // a wave takes 2048 contiguous ids, 32 rounds of 64: one or two owners per wave
+constexpr int XCHG_ROUNDS = XCHG_IDS_PER_WAVE / 64;
+constexpr int XCHG_BATCH = 8;                            // rounds whose gathers are in flight together (k_xchg_pack)
+constexpr int XCHG_IDS_PER_BLOCK = XCHG_IDS_PER_WAVE * (XCHG_THREADS / 64);    // 32768 ids per block: ~100 blocks, a couple of hundred
+                                              // global atomics per call in all.  (Atomics on one address are serialised by the L2: one per
+                                              // wave and round on the 2 N counters was 0.7 ms per launch.)
+
+// bit r of the result: the flag of id w0 + 64 r + lane (ids >= n read as unflagged).  A wave whose whole range is below n (all
+// but the last) loads unguarded, 32 loads in flight off one address register: a load behind a branch waits for itself, and the
+// rounds ran one memory round trip after the other (0.1 ms per launch).
+__device__ __forceinline__ uint32_t xchg_load_flags(const uint8_t* __restrict__ flag, int64_t w0, int lane, int64_t n) {
+    uint32_t bits = 0;
+    if (w0 + XCHG_IDS_PER_WAVE <= n) {
+        const uint8_t* p = flag + w0 + lane;
+#pragma unroll
+        for (int r = 0; r < XCHG_ROUNDS; r++) bits |= (uint32_t)(p[64 * r] != 0) << r;
+    } else {
+        for (int r = 0; r < XCHG_ROUNDS; r++) {
+            const int64_t i = w0 + 64 * r + lane;
+            bits |= (uint32_t)(i < n && flag[i] != 0) << r;
+        }
     }
-    return place;
+    return bits;
 }
 
-constexpr int XCHG_IDS_PER_BLOCK = 8192;      // a block takes a contiguous chunk of ids: a few hundred global atomics per call in all
-                                              // (one atomic per wave on the 2 N counters -- the same few addresses -- was 0.7 ms: atomics on
-                                              // one address are serialised by the L2)
+// flagged ids of the wave's range that belong to the owner whose slice is [lo, hi) (relative to the wave's first id); wave-uniform
+__device__ __forceinline__ uint32_t xchg_wave_count(uint32_t bits, int lane, int lo, int hi) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < XCHG_ROUNDS; r++) {
+        const int rel = 64 * r + lane;
+        cnt += (uint32_t)__popcll(__ballot(((bits >> r) & 1u) && rel >= lo && rel < hi));
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ int xchg_hi(int lo, int S) { const int64_t h = (int64_t)lo + S; return h < XCHG_IDS_PER_WAVE ? (int)h : XCHG_IDS_PER_WAVE; }
+
+// the owners [o0, o1] a wave's ids [w0, w0 + XCHG_IDS_PER_WAVE) & [0, n) fall to, slices of S ids; false: no id of the wave is < n
+__device__ __forceinline__ bool xchg_wave_owners(int64_t w0, int64_t n, int S, int& o0, int& o1) {
+    if (w0 >= n) return false;
+    const int64_t last = (w0 + XCHG_IDS_PER_WAVE - 1 < n ? w0 + XCHG_IDS_PER_WAVE - 1 : n - 1);
+    o0 = (int)((uint32_t)w0 / (uint32_t)S); o1 = (int)((uint32_t)last / (uint32_t)S);       // (ids < 2^31; wave-uniform: scalar divisions)
+    return true;
+}
 
 __global__ void __launch_bounds__(256)
 k_xchg_mark(int B, int F, const int32_t* __restrict__ faces, const uint32_t* __restrict__ tiles_touched,
@@ -60,85 +84,159 @@ k_xchg_mark(int B, int F, const int32_t* __restrict__ faces, const uint32_t* __r
     flag_v[faces[3 * (int64_t)f]] = 1; flag_v[faces[3 * (int64_t)f + 1]] = 1; flag_v[faces[3 * (int64_t)f + 2]] = 1;
 }
 
-// flagged ids of [i0, i0 + XCHG_IDS_PER_BLOCK) per owner, counted in LDS first
-__global__ void __launch_bounds__(256)
+// flagged ids per owner: a ballot count per wave and owner, summed in LDS, one global atomic per block and owner
+__global__ void __launch_bounds__(XCHG_THREADS)
 k_xchg_count(int P, int F, int N, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
              uint32_t* __restrict__ counts) {
     __shared__ uint32_t s_cnt[2 * XCHG_MAX_RANKS];
-    for (int k = threadIdx.x; k < 2 * N; k += 256) s_cnt[k] = 0;
+    for (int k = threadIdx.x; k < 2 * N; k += XCHG_THREADS) s_cnt[k] = 0;
     __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK;
-    // (all of the block's flags first: with the loads inside the loop every iteration waited for its own round trip to memory,
-    // 0.1 ms per launch; whole waves, uniform trip count)
-    uint8_t ff[XCHG_IDS_PER_BLOCK / 256], fv[XCHG_IDS_PER_BLOCK / 256];
-#pragma unroll
-    for (int r = 0; r < XCHG_IDS_PER_BLOCK / 256; r++) {
-        const int64_t i = i0 + r * 256 + threadIdx.x;
-        ff[r] = i < F ? flag_f[i] : 0; fv[r] = i < P ? flag_v[i] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < XCHG_IDS_PER_BLOCK / 256; r++) {
-        const int64_t i = i0 + r * 256 + threadIdx.x;
-        const bool af = ff[r] != 0, av = fv[r] != 0;
-        wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
-        wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
-    }
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * XCHG_IDS_PER_WAVE;
+    const uint32_t ff = xchg_load_flags(flag_f, w0, lane, F);
+    __builtin_amdgcn_sched_barrier(0);                  // (32 loads in flight at a time: with all 64 the kernel spills)
+    const uint32_t fv = xchg_load_flags(flag_v, w0, lane, P);
+    __builtin_amdgcn_sched_barrier(0);
+    int o0, o1;
+    if (xchg_wave_owners(w0, F, Fs, o0, o1))
+        for (int o = o0; o <= o1; o++) {
+            const int lo = (int)((int64_t)o * Fs - w0);
+            const uint32_t c = xchg_wave_count(ff, lane, lo, xchg_hi(lo, Fs));
+            if (lane == 0 && c) atomicAdd(&s_cnt[2 * o], c);
+        }
+    if (xchg_wave_owners(w0, P, Ps, o0, o1))
+        for (int o = o0; o <= o1; o++) {
+            const int lo = (int)((int64_t)o * Ps - w0);
+            const uint32_t c = xchg_wave_count(fv, lane, lo, xchg_hi(lo, Ps));
+            if (lane == 0 && c) atomicAdd(&s_cnt[2 * o + 1], c);
+        }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * N; k += 256) if (s_cnt[k]) atomicAdd(counts + k, s_cnt[k]);
+    for (int k = threadIdx.x; k < 2 * N; k += XCHG_THREADS) if (s_cnt[k]) atomicAdd(counts + k, s_cnt[k]);
 }
 
-// the rows of the block's chunk of ids: counted per owner in LDS, ONE global atomic per (block, owner, kind) reserves their
-// places in the owner's segment, the rows take them in whatever order the LDS cursor hands out
-__global__ void __launch_bounds__(256)
+// the rows of the block's chunk of ids: counted per owner in LDS as above, ONE global atomic per (block, owner, kind) reserves their
+// places in the owner's segment, every wave takes its share of the block's places with one LDS atomic per owner and hands
+// them out by ballot rank (the order of the rows inside a segment is free: the owner adds rows with distinct ids)
+__global__ void __launch_bounds__(XCHG_THREADS)
 k_xchg_pack(int B, int P, int F, int N, int Ps, int Fs, const uint8_t* __restrict__ flag_f, const uint8_t* __restrict__ flag_v,
             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, const float* __restrict__ dverts,
             const float* __restrict__ dcolor, const float* __restrict__ dopacity, const float* __restrict__ dintense,
             float* __restrict__ send) {
     __shared__ uint32_t s_cnt[2 * XCHG_MAX_RANKS], s_base[2 * XCHG_MAX_RANKS], s_seg[XCHG_MAX_RANKS + 1];
-    for (int k = threadIdx.x; k < 2 * N; k += 256) s_cnt[k] = 0;
+    for (int k = threadIdx.x; k < 2 * N; k += XCHG_THREADS) s_cnt[k] = 0;
     if (threadIdx.x == 0) {
         uint32_t off = 0;
         for (int o = 0; o < N; o++) { s_seg[o] = off; off += counts[2 * o] * (uint32_t)(2 + B) + counts[2 * o + 1] * 7u; }
     }
     __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK;
-    uint8_t ff[XCHG_IDS_PER_BLOCK / 256], fv[XCHG_IDS_PER_BLOCK / 256];      // (all of the block's flags first, see k_xchg_count)
-#pragma unroll
-    for (int r = 0; r < XCHG_IDS_PER_BLOCK / 256; r++) {
-        const int64_t i = i0 + r * 256 + threadIdx.x;
-        ff[r] = i < F ? flag_f[i] : 0; fv[r] = i < P ? flag_v[i] : 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = (int64_t)blockIdx.x * XCHG_IDS_PER_BLOCK + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * XCHG_IDS_PER_WAVE;
+    const uint32_t ff = xchg_load_flags(flag_f, w0, lane, F);
+    __builtin_amdgcn_sched_barrier(0);                  // (32 loads in flight at a time: with all 64 the kernel spills)
+    const uint32_t fv = xchg_load_flags(flag_v, w0, lane, P);
+    __builtin_amdgcn_sched_barrier(0);
+    int of0 = 0, of1 = -1, ov0 = 0, ov1 = -1;
+    xchg_wave_owners(w0, F, Fs, of0, of1);
+    xchg_wave_owners(w0, P, Ps, ov0, ov1);
+    for (int o = of0; o <= of1; o++) {
+        const int lo = (int)((int64_t)o * Fs - w0);
+        const uint32_t c = xchg_wave_count(ff, lane, lo, xchg_hi(lo, Fs));
+        if (lane == 0 && c) atomicAdd(&s_cnt[2 * o], c);
     }
-#pragma unroll
-    for (int r = 0; r < XCHG_IDS_PER_BLOCK / 256; r++) {
-        const int64_t i = i0 + r * 256 + threadIdx.x;
-        const bool af = ff[r] != 0, av = fv[r] != 0;
-        wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
-        wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
+    for (int o = ov0; o <= ov1; o++) {
+        const int lo = (int)((int64_t)o * Ps - w0);
+        const uint32_t c = xchg_wave_count(fv, lane, lo, xchg_hi(lo, Ps));
+        if (lane == 0 && c) atomicAdd(&s_cnt[2 * o + 1], c);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * N; k += 256) { s_base[k] = s_cnt[k] ? atomicAdd(cursors + k, s_cnt[k]) : 0u; s_cnt[k] = 0; }
+    for (int k = threadIdx.x; k < 2 * N; k += XCHG_THREADS) { s_base[k] = s_cnt[k] ? atomicAdd(cursors + k, s_cnt[k]) : 0u; s_cnt[k] = 0; }
     __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int o = of0; o <= of1; o++) {
+        const int lo = (int)((int64_t)o * Fs - w0), hi = xchg_hi(lo, Fs);
+        const uint32_t c = xchg_wave_count(ff, lane, lo, hi);
+        if (!c) continue;
+        uint32_t place = 0;
+        if (lane == 0) place = atomicAdd(&s_cnt[2 * o], c);
+        place = (uint32_t)__builtin_amdgcn_readfirstlane((int)place) + s_base[2 * o];
+        float* seg = send + s_seg[o];
+        // XCHG_BATCH rounds at a time: all of the batch's gathers first (unguarded, from row 0 for idle lanes), then its stores --
+        // a load behind a branch, or behind the previous round's stores, waits for itself and the rounds ran one memory round
+        // trip after the other
+#pragma unroll 1
+        for (int r0 = 0; r0 < XCHG_ROUNDS; r0 += XCHG_BATCH) {
+            float op[XCHG_BATCH];
 #pragma unroll
-    for (int r = 0; r < XCHG_IDS_PER_BLOCK / 256; r++) {
-        const int64_t i = i0 + r * 256 + threadIdx.x;
-        const bool af = ff[r] != 0, av = fv[r] != 0;
-        const uint32_t pfl = wave_slot_place(s_cnt, 2u * (uint32_t)(af ? i / Fs : 0), af);
-        const uint32_t pvl = wave_slot_place(s_cnt, 2u * (uint32_t)(av ? i / Ps : 0) + 1u, av);
-        if (af) {
-            const int o = (int)(i / Fs);
-            const uint32_t pf = s_base[2 * o] + pfl;
-            float* dst = send + s_seg[o] + (size_t)pf * (size_t)(2 + B);
-            dst[0] = __int_as_float((int)i);                           // (the id's bits travel in a float slot)
-            dst[1] = dopacity[i];
-            for (int b = 0; b < B; b++) dst[2 + b] = dintense[(int64_t)b * F + i];
+            for (int k = 0; k < XCHG_BATCH; k++) {
+                const int rel = 64 * (r0 + k) + lane;
+                const bool act = ((ff >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                op[k] = dopacity[act ? w0 + rel : 0];
+            }
+            uint32_t pl = place;
+#pragma unroll
+            for (int k = 0; k < XCHG_BATCH; k++) {
+                const int rel = 64 * (r0 + k) + lane;
+                const bool act = ((ff >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                const unsigned long long m = __ballot(act);
+                if (act) {
+                    float* dst = seg + (size_t)(pl + (uint32_t)__popcll(m & below)) * (size_t)(2 + B);
+                    dst[0] = __int_as_float((int)(w0 + rel)); dst[1] = op[k];      // (the id's bits travel in a float slot)
+                }
+                pl += (uint32_t)__popcll(m);
+            }
+            for (int b = 0; b < B; b++) {
+                const float* src = dintense + (int64_t)b * F;
+#pragma unroll
+                for (int k = 0; k < XCHG_BATCH; k++) {
+                    const int rel = 64 * (r0 + k) + lane;
+                    const bool act = ((ff >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                    op[k] = src[act ? w0 + rel : 0];
+                }
+                pl = place;
+#pragma unroll
+                for (int k = 0; k < XCHG_BATCH; k++) {
+                    const int rel = 64 * (r0 + k) + lane;
+                    const bool act = ((ff >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                    const unsigned long long m = __ballot(act);
+                    if (act) seg[(size_t)(pl + (uint32_t)__popcll(m & below)) * (size_t)(2 + B) + 2 + b] = op[k];
+                    pl += (uint32_t)__popcll(m);
+                }
+            }
+            place = pl;
         }
-        if (av) {
-            const int o = (int)(i / Ps);
-            const uint32_t pv = s_base[2 * o + 1] + pvl;
-            float* dst = send + s_seg[o] + (size_t)counts[2 * o] * (size_t)(2 + B) + (size_t)pv * 7u;
-            dst[0] = __int_as_float((int)i);
-            dst[1] = dverts[3 * i]; dst[2] = dverts[3 * i + 1]; dst[3] = dverts[3 * i + 2];
-            dst[4] = dcolor[3 * i]; dst[5] = dcolor[3 * i + 1]; dst[6] = dcolor[3 * i + 2];
+    }
+    for (int o = ov0; o <= ov1; o++) {
+        const int lo = (int)((int64_t)o * Ps - w0), hi = xchg_hi(lo, Ps);
+        const uint32_t c = xchg_wave_count(fv, lane, lo, hi);
+        if (!c) continue;
+        uint32_t place = 0;
+        if (lane == 0) place = atomicAdd(&s_cnt[2 * o + 1], c);
+        place = (uint32_t)__builtin_amdgcn_readfirstlane((int)place) + s_base[2 * o + 1];
+        float* seg = send + s_seg[o] + (size_t)counts[2 * o] * (size_t)(2 + B);
+#pragma unroll 1
+        for (int r0 = 0; r0 < XCHG_ROUNDS; r0 += XCHG_BATCH) {
+            float g[XCHG_BATCH][6];
+#pragma unroll
+            for (int k = 0; k < XCHG_BATCH; k++) {
+                const int rel = 64 * (r0 + k) + lane;
+                const bool act = ((fv >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                const int64_t i = act ? w0 + rel : 0;
+                g[k][0] = dverts[3 * i]; g[k][1] = dverts[3 * i + 1]; g[k][2] = dverts[3 * i + 2];
+                g[k][3] = dcolor[3 * i]; g[k][4] = dcolor[3 * i + 1]; g[k][5] = dcolor[3 * i + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < XCHG_BATCH; k++) {
+                const int rel = 64 * (r0 + k) + lane;
+                const bool act = ((fv >> (r0 + k)) & 1u) && rel >= lo && rel < hi;
+                const unsigned long long m = __ballot(act);
+                if (act) {
+                    float* dst = seg + (size_t)(place + (uint32_t)__popcll(m & below)) * 7u;
+                    dst[0] = __int_as_float((int)(w0 + rel));
+#pragma unroll
+                    for (int c = 0; c < 6; c++) dst[1 + c] = g[k][c];
+                }
+                place += (uint32_t)__popcll(m);
+            }
         }
     }
 }
@@ -175,7 +273,7 @@ hipError_t launch_exchange_mark(int B, int P, int F, int N, const int32_t* faces
     uint8_t* flag_f = flags; uint8_t* flag_v = flags + F;
     hipLaunchKernelGGL(k_xchg_mark, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, B, F, faces, tiles_touched, flag_f, flag_v);
     const int64_t m = P > F ? P : F;
-    hipLaunchKernelGGL(k_xchg_count, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(256), 0, st, P, F, N, Ps, Fs, flag_f, flag_v, counts);
+    hipLaunchKernelGGL(k_xchg_count, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(XCHG_THREADS), 0, st, P, F, N, Ps, Fs, flag_f, flag_v, counts);
     return hipSuccess;
 }
 
@@ -187,7 +285,7 @@ hipError_t launch_exchange_pack(int B, int P, int F, int N, const uint8_t* flags
     if (F == 0 || P == 0) return hipSuccess;
     const int Fs = (F + N - 1) / N, Ps = (P + N - 1) / N;
     const int64_t m = P > F ? P : F;
-    hipLaunchKernelGGL(k_xchg_pack, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(256), 0, st, B, P, F, N, Ps, Fs, flags, flags + F,
+    hipLaunchKernelGGL(k_xchg_pack, dim3((unsigned)((m + XCHG_IDS_PER_BLOCK - 1) / XCHG_IDS_PER_BLOCK)), dim3(XCHG_THREADS), 0, st, B, P, F, N, Ps, Fs, flags, flags + F,
                        counts, cursors, dverts, dcolor, dopacity, dintense, send);
     return hipSuccess;
 }

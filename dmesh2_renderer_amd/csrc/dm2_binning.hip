@@ -104,6 +104,9 @@ __device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, 
 // tile list.  `d` is read only then.  (A/B at cfg4: packing in a kernel of its own behind the plan's read-back, so that
 // it runs while the host sizes and enqueues the run step, costs more than it hides -- the binning part alone is bound by
 // its atomics, 0.08 ms, which here disappear behind the record traffic: 0.16 ms fused against 0.08 + 0.13 ms split.)
+#ifndef DM2_PRE_COALESCE
+#define DM2_PRE_COALESCE 1
+#endif
 #ifndef DM2_PRE_WAVES
 #define DM2_PRE_WAVES 1
 #endif
@@ -204,6 +207,35 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     fs.tiles_touched[idx] = touched;
     fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
     fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
+#if DM2_PRE_COALESCE
+    // The records leave through LDS, a 128-B half at a time, so that every store instruction writes whole 128-B lines (8 lanes
+    // per line).  A lane storing its own record 16 B per instruction leaves 64 partially written lines per instruction to the
+    // L2, which evicts part of them before the rest of the line arrives: WRITE_SIZE 386 MB for 296 MB of stores at cfg 4.
+    __shared__ uint4 s_t[PACK ? 4 : 1][PACK ? 64 * 8 : 1];
+    const unsigned long long tmask = __ballot(touched != 0);
+    if (PACK && tmask != 0ull && __ballot(true) == ~0ull) {                // (whole waves; wave-uniform)
+        FaceRec r;
+        if (touched != 0) { pack_face(d, b, f, i1, r); r.pad[0] = 0.f; }
+        const uint4* src = reinterpret_cast<const uint4*>(&r);
+        const int lane = (int)(threadIdx.x & 63);
+        uint4* sw = s_t[threadIdx.x >> 6];
+        uint4* dst = fs.recs + (idx - lane) * FACE_REC_U4;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (touched != 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) sw[lane * 8 + (k ^ (lane & 7))] = src[half * 8 + k];    // (swizzled: 8 lanes cover the 32 banks)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int rr = j * 8 + (lane >> 3), c = lane & 7;
+                if ((tmask >> rr) & 1ull) dst[(int64_t)rr * FACE_REC_U4 + half * 8 + c] = sw[rr * 8 + (c ^ (rr & 7))];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    } else
+#endif
     if (PACK && touched != 0) {
         FaceRec r;
         pack_face(d, b, f, i1, r);

@@ -202,7 +202,7 @@ size_t dm2_scratch_bytes(int kind, int64_t count, int64_t aux) {
 }
 
 static int forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
-                        int64_t* max_tile_entries, int64_t* pair_bound, uint2* ranges_to_clear) {
+                        int64_t* max_tile_entries, int64_t* pair_bound, uint2* ranges_to_clear, uint32_t* tile_order) {
     if (check_render_desc(d)) return 1;
     if (!num_rendered || !max_tile_entries) return fail("num_rendered / max_tile_entries is null");
     hipStream_t st = (hipStream_t)stream;
@@ -215,14 +215,14 @@ static int forward_plan(const dm2_render_desc* d, void* face_scratch, size_t fac
     uint32_t* host_meta = nullptr; uint32_t seq = 0;
     if (plan_meta_prepare(&host_meta, &seq)) return 1;
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, d->patch_min, d->faces, d->verts_ndc, d->verts_image, fs, d,
-                                        host_meta, seq, ranges_to_clear, st));
+                                        host_meta, seq, ranges_to_clear, tile_order, st));
     DM2_HIP(hipGetLastError());
     return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries, pair_bound);
 }
 
 int dm2_forward_plan(const dm2_render_desc* d, void* face_scratch, size_t face_bytes, void* stream, int64_t* num_rendered,
                      int64_t* max_tile_entries, int64_t* pair_bound) {
-    return forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, nullptr);
+    return forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, nullptr, nullptr);
 }
 
 static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t max_tile_entries, int64_t pair_bound, void* face_scratch, size_t face_bytes,
@@ -244,9 +244,10 @@ static int forward_run(const dm2_render_desc* d, int64_t num_rendered, int64_t m
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn), nullptr, binning_bytes);
         is.face_recs = fs.recs;
         DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
-                                     fs.depths, fs, bs, is.ranges, ranges_cleared, st));   // renderer.cu:192
+                                     fs.depths, fs, bs, is.ranges, ranges_cleared, is.tile_order, st));   // renderer.cu:192
     } else {
         DM2_HIP(hipMemsetAsync(is.ranges, 0, (size_t)Tn * sizeof(uint2), st));
+        dm2::launch_tile_order_identity(Tn, is.tile_order, st);
     }
     // the pair pool is used when the caller appended room for every pair the plan counted (a smaller appendix is ignored)
     const bool use_pool = have_faces && pair_bound > 0 && bs.pool_cap >= pair_bound && !(d->flags & DM2_FLAG_NO_PAIR_POOL);
@@ -272,9 +273,12 @@ int dm2_forward(const dm2_render_desc* d, void* face_scratch, size_t face_bytes,
     if (forward_mode) *forward_mode = DM2_FWD_NONE;
     const int64_t N = (int64_t)d->B * d->H * d->W, Tn = tiles_of(d->B, d->W, d->H);
     // the image scratch is at hand already: the plan's last kernel clears the tile ranges, one launch less in the run step
-    uint2* ranges = nullptr;
-    if (N > 0 && image_scratch && dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) <= image_bytes) ranges = dm2::ImageState::carve(image_scratch, N, Tn).ranges;
-    if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, ranges)) return 1;
+    uint2* ranges = nullptr; uint32_t* tile_order = nullptr;
+    if (N > 0 && image_scratch && dm2_scratch_bytes(DM2_SCRATCH_IMAGE, N, Tn) <= image_bytes) {
+        const dm2::ImageState is0 = dm2::ImageState::carve(image_scratch, N, Tn);
+        ranges = is0.ranges; tile_order = is0.tile_order;
+    }
+    if (forward_plan(d, face_scratch, face_bytes, stream, num_rendered, max_tile_entries, pair_bound, ranges, tile_order)) return 1;
     const bool planned = d->P != 0 && (int64_t)d->B * d->F != 0 && Tn != 0;     // (otherwise no plan kernel ran)
     const bool wants_pool = d->aa_temperature > 0.0f && !(d->flags & (DM2_FLAG_NO_BACKWARD | DM2_FLAG_LEGACY_KERNELS | DM2_FLAG_NO_PAIR_POOL));
     if (dm2_scratch_bytes(DM2_SCRATCH_BINNING, *num_rendered, Tn) + (wants_pool ? dm2_scratch_bytes(DM2_SCRATCH_PAIR_POOL, *pair_bound, 0) : 0) > binning_bytes)
@@ -342,7 +346,7 @@ int dm2_layers_plan(const dm2_layers_desc* d, void* face_scratch, size_t face_by
     uint32_t* host_meta = nullptr; uint32_t seq = 0;
     if (plan_meta_prepare(&host_meta, &seq)) return 1;
     DM2_HIP(dm2::launch_preprocess_scan(d->B, d->P, d->F, d->W, d->H, nullptr, d->faces, d->verts_ndc, d->verts_image, fs, nullptr,
-                                        host_meta, seq, nullptr, st));
+                                        host_meta, seq, nullptr, nullptr, st));
     DM2_HIP(hipGetLastError());
     return plan_meta_wait(fs.plan_meta, st, num_rendered, max_tile_entries, nullptr);
 }
@@ -365,7 +369,7 @@ int dm2_layers_run(const dm2_layers_desc* d, int64_t num_rendered, int64_t max_t
         fs = dm2::FaceState::carve(face_scratch, BF, Tn, dm2::scan_temp_bytes(BF), false);
         bs = dm2::BinningState::carve(binning_scratch, num_rendered, dm2::sort_temp_bytes(num_rendered, Tn));
         DM2_HIP(dm2::launch_bin_sort(d->B, d->F, d->W, d->H, num_rendered, max_tile_entries, (d->flags & DM2_FLAG_LEGACY_KERNELS) != 0,
-                                     fs.min_depths, fs, bs, ls.ranges, false, st));   // renderer.cu:603
+                                     fs.min_depths, fs, bs, ls.ranges, false, nullptr, st));   // renderer.cu:603
     } else {
         DM2_HIP(hipMemsetAsync(ls.ranges, 0, (size_t)Tn * sizeof(uint2), st));
     }

@@ -24,6 +24,7 @@
 //   k_tile_ranges  renderer.cu:470-492 [start,end) of every tile in the sorted list
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>   // rocprim's texture_cache_iterator.hpp calls host memset without including it
 #include <rocprim/rocprim.hpp>
 
@@ -329,6 +330,82 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     }
 }
 
+// Block -> tile order of the composite kernels (dm2_pairs.h tile_of_block): XCD x (blocks x, x + 8, ...) keeps its contiguous
+// band of ceil(Tn / 8) tiles and takes them by list length.  The hardware hands the next block to whichever slot frees up, so
+// a kernel ends when its unluckiest slot does; in index order the last round starts tiles of every length (6 % above the mean
+// load in a model of 1080p / 1 M faces: 8 rounds of 1024 resident blocks, lists of 195 +- 19 entries;
+// tools/tile_order_sim.py), with the short lists at the end the slots run dry together.  Against that stands the locality of
+// index order: neighbouring tiles share faces, whose records and gradient rows then meet in the XCD's L2.  Two modes, chosen by
+// the number of rounds (A/B of the three orders on one MI355X, step ms, profiles/r03_ab_tile_order.txt):
+//   TILE_ORDER_ALL   the whole band longest list first             cfg 4: 1.968 (index order) -> 1.934, point-sampled 1.532 ->
+//                    (up to 16 rounds: the tail is what counts)     1.502, B = 4: 1.349 -> 1.330, cfg 2: 0.310 -> 0.305;
+//                                                                   cfg 5 (32 rounds): 6.29 -> 6.33, its backward + 3 %
+//   TILE_ORDER_TAIL  index order, but the quarter of the band with  cfg 5: 6.29 -> 6.25 (cfg 4: 1.946)
+//                    the shortest lists last, longest first
+// A counting sort over 256 length classes; inside a class the order is whatever the atomics give (it is only an order of
+// execution).  One block per XCD band; cnt == nullptr: index order.  Runs in the plan-to-run gap when the image scratch is at
+// hand.
+enum { TILE_ORDER_INDEX = 0, TILE_ORDER_TAIL = 1, TILE_ORDER_ALL = 2 };
+#ifndef DM2_TILE_ORDER
+#define DM2_TILE_ORDER -1       // (A/B builds: force one of the modes)
+#endif
+static int tile_order_mode(int64_t Tn) {
+    if (DM2_TILE_ORDER >= 0) return DM2_TILE_ORDER;
+    const char* e = getenv("DM2_TILE_ORDER_MODE");                   // (tests: every mode on one small frame)
+    if (e && *e >= '0' && *e <= '2') return *e - '0';
+    return Tn <= 16 * 1024 ? TILE_ORDER_ALL : TILE_ORDER_TAIL;      // (1024 resident workgroups at 4 per CU)
+}
+__global__ void __launch_bounds__(1024)
+k_tile_order(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cnt_big, const uint32_t* __restrict__ meta,
+             uint32_t* __restrict__ order, int mode) {
+    __shared__ uint32_t s_h[257];
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_k;
+    const int64_t per = (Tn + 7) / 8, t0 = (int64_t)blockIdx.x * per;
+    const int64_t n = t0 >= Tn ? 0 : (Tn - t0 < per ? Tn - t0 : per);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int64_t i = n + tid; i < per; i += 1024) order[t0 + i] = 0xFFFFFFFFu;        // (blocks behind the band's last tile leave at once)
+    if (!cnt || mode == TILE_ORDER_INDEX) { for (int64_t i = tid; i < n; i += 1024) order[t0 + i] = (uint32_t)(t0 + i); return; }
+    const uint32_t mx = meta[1] ? meta[1] : 1u;                                        // the longest list (k_tile_scan)
+    auto cls = [&](int64_t t) { const uint64_t c = (uint64_t)cnt[t] + cnt_big[t]; const uint64_t q = c * 255u / mx; return 255u - (uint32_t)(q > 255u ? 255u : q); };
+    if (tid < 257) s_h[tid] = 0;
+    if (tid == 0) s_k = 255u;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) atomicAdd(&s_h[cls(t0 + i)], 1u);
+    __syncthreads();
+    {   // exclusive scan of the 256 class sizes (class 0 = the longest lists): s_h[k] = tiles in front of class k, longest first
+        const uint32_t v = tid < 256 ? s_h[tid] : 0u;
+        const uint32_t inc = (uint32_t)wave_inclusive_scan((int)v);
+        if (tid < 256 && lane == 63) s_w[wid] = inc;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t before = 0;
+            for (int w = 0; w < wid; w++) before += s_w[w];
+            s_h[tid] = before + inc - v;
+            // the head: classes 0..K, K the first class with which three quarters of the band are in
+            if (mode == TILE_ORDER_TAIL && (uint64_t)(before + inc) * 4u >= (uint64_t)n * 3u) atomicMin(&s_k, (uint32_t)tid);
+        }
+    }
+    __syncthreads();
+    const uint32_t K = s_k;                                                            // (TILE_ORDER_ALL: no head, everything by class)
+    __syncthreads();                                                                   // (s_w is reused below)
+    uint32_t carry = 0;                                                                // head tiles placed so far
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const uint32_t c = i < n ? cls(t0 + i) : 0xFFFFFFFFu;
+        const bool head = i < n && mode == TILE_ORDER_TAIL && c <= K;
+        const unsigned long long m = __ballot(head);
+        if (lane == 0) s_w[wid] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t v = s_w[w]; if (w < wid) before += v; total += v; }
+        if (head) order[t0 + carry + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(t0 + i);
+        else if (i < n) order[t0 + atomicAdd(&s_h[c], 1u)] = (uint32_t)(t0 + i);       // (the tail's classes start behind the head)
+        carry += total;
+        __syncthreads();
+    }
+}
+
 // (depth bits | face id) of every list entry into its tile's segment [tile_start, tile_start + count): entries of faces
 // with at most four tiles at the place the plan gave them, entries of larger faces behind those, wherever the cursor
 // (ranges[t].y, zeroed) puts them -- k_tile_sort orders the segment.
@@ -533,9 +610,13 @@ size_t sort_temp_bytes(int64_t R, int64_t Tn) {
     return bytes;
 }
 
+void launch_tile_order_identity(int64_t Tn, uint32_t* tile_order, hipStream_t st) {
+    if (Tn > 0) hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, Tn, nullptr, nullptr, nullptr, tile_order, (int)TILE_ORDER_INDEX);
+}
+
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, hipStream_t st) {
+                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, uint32_t* tile_order, hipStream_t st) {
     const int64_t BF = (int64_t)B * F;
     if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -551,14 +632,19 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
                            dm2_render_desc{});
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.pair_part, fs.plan_meta,
                        host_meta, host_seq, ranges_to_clear);
+    // (behind the kernel whose last store the host is polling for: it runs while the host sizes and enqueues the run step)
+    if (tile_order) hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.plan_meta, tile_order, tile_order_mode(Tn));
     return hipSuccess;
 }
 
 hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
-                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, hipStream_t st) {
+                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, uint32_t* tile_order, hipStream_t st) {
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
     if (!ranges_cleared) launch_zero_words(ranges, 2 * Tn, st);            // renderer.cu:211 (or done by the plan's last kernel)
+    // tile_order: the composite kernels' block -> tile table, wanted and not yet written by the plan (which did both or neither)
+    if (tile_order && !ranges_cleared)
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, Tn, R > 0 ? fs.tile_cnt : nullptr, fs.tile_cnt_big, fs.plan_meta, tile_order, tile_order_mode(Tn));
     hipError_t e = hipSuccess;
     if (R <= 0) return e;
     const int64_t BF = (int64_t)B * F;

@@ -41,20 +41,23 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     __shared__ FpQuick s_quick[FP_CHUNK];
     __shared__ float s_ro[3];
 
-    const int b = blockIdx.z;
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
+    uint32_t tile;
+    if (!tile_of_block(gx * gy * (uint32_t)d.B, is.tile_order, tile)) return;    // XCD-contiguous bands, longest list first (dm2_pairs.h)
+    const int b = (int)(tile / (gx * gy));
+    const uint32_t tyx = tile - (uint32_t)b * gx * gy;
+    const uint32_t tile_y = tyx / gx, tile_x = tyx - tile_y * gx;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t lx = tid & 15, ly = tid >> 4;
-    const uint32_t px = blockIdx.x * TILE + lx, py = blockIdx.y * TILE + ly;
+    const uint32_t px = tile_x * TILE + lx, py = tile_y * TILE + ly;
     const bool inside = (px < (uint32_t)d.W) && (py < (uint32_t)d.H);
     const int64_t pix = ((int64_t)b * d.H + py) * d.W + px;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) hit_valid[0] = 1u;   // the masks of this launch are current
+    if (blockIdx.x == 0 && tid == 0) hit_valid[0] = 1u;   // the masks of this launch are current
 
     f3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) {
         pixel_ray(d, b, pix, px + (uint32_t)d.patch_min[2 * b], py + (uint32_t)d.patch_min[2 * b + 1], d.full_W, d.full_H, ro, rd);
     }
-    const uint32_t tile = ((uint32_t)b * gy + blockIdx.y) * gx + blockIdx.x;
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     // do all rays of the tile share their origin (pixel (0,0) of the tile is always inside the image)?
@@ -160,7 +163,7 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,
                                  uint32_t* hit_valid, hipStream_t st) {
-    const dim3 grid((d.W + TILE - 1) / TILE, (d.H + TILE - 1) / TILE, d.B);
+    const dim3 grid(tile_grid_blocks((uint32_t)(((d.W + TILE - 1) / TILE) * ((d.H + TILE - 1) / TILE) * d.B)));
     StageTimer tm(ST_FWD, st);
     hipLaunchKernelGGL(k_render_forward_point, grid, dim3(TILE_PIX), 0, st, d, ranges, face_list, is, out_color, out_depth,
                        out_tri_cnt, hit_masks, hit_valid);

@@ -93,7 +93,7 @@ k_render_forward_queue(dm2_render_desc d, const uint2* __restrict__ ranges, cons
 
     const uint32_t gx = (d.W + TILE - 1) / TILE, gy = (d.H + TILE - 1) / TILE;
     uint32_t tile;
-    if (!tile_of_block(gx * gy * (uint32_t)d.B, tile)) return;    // XCD-contiguous tile order (dm2_pairs.h)
+    if (!tile_of_block(gx * gy * (uint32_t)d.B, is.tile_order, tile)) return;    // XCD-contiguous tile order (dm2_pairs.h)
     const int b = (int)(tile / (gx * gy));
     const uint32_t tyx = tile - (uint32_t)b * gx * gy;
     const int tile_y = (int)(tyx / gx), tile_x = (int)(tyx - (uint32_t)tile_y * gx);

@@ -29,9 +29,10 @@ namespace dm2 {
 // block L renders tile (L % 8) * ceil(Tn / 8) + L / 8 gives every XCD one contiguous band of tiles, so a face record
 // is fetched into one L2 instead of up to eight.  (Only an ordering: correctness does not depend on where a block runs.)
 __host__ __device__ __forceinline__ uint32_t tile_grid_blocks(uint32_t Tn) { return 8u * ((Tn + 7u) / 8u); }
-__device__ __forceinline__ bool tile_of_block(uint32_t Tn, uint32_t& tile) {
+// Inside its band an XCD takes the tiles in the order of `order` (k_tile_order, dm2_binning.hip: longest list first).
+__device__ __forceinline__ bool tile_of_block(uint32_t Tn, const uint32_t* __restrict__ order, uint32_t& tile) {
     const uint32_t per = (Tn + 7u) / 8u;
-    tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    tile = order[(blockIdx.x & 7u) * per + (blockIdx.x >> 3)];
     return tile < Tn;
 }
 

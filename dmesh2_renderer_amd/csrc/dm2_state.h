@@ -78,11 +78,13 @@ struct ImageState {
     uint32_t* n_contrib;      // (N)
     uint2* ranges;            // (Tn) [start,end) into face_list
     uint32_t* tile_max_lc;    // (Tn) the largest n_contrib of the tile's pixels (written by the dense and the point-sampled forward)
+    uint32_t* tile_order;     // (8 ceil(Tn / 8)) block -> tile of the composite kernels (k_tile_order, dm2_pairs.h tile_of_block)
     const uint4* face_recs;   // not part of the image scratch: FaceState::recs of the same forward, set by the host API
     static ImageState carve(void* base, int64_t N, int64_t Tn, size_t* total = nullptr) {
         Carver c(base); ImageState s; s.face_recs = nullptr;
         s.final_T = c.take<float>(N); s.final_prev_T = c.take<float>(N); s.n_contrib = c.take<uint32_t>(N);
         s.ranges = c.take<uint2>(Tn); s.tile_max_lc = c.take<uint32_t>(Tn);
+        s.tile_order = c.take<uint32_t>(8 * ((Tn + 7) / 8));
         if (total) *total = c.used(base) + ALIGN;
         return s;
     }
@@ -156,14 +158,17 @@ unsigned sort_end_bit(int64_t Tn);
 // ranges_to_clear != nullptr: the last kernel also zeroes these Tn tile ranges (what the run step would do first)
 hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32_t* patch_min, const int32_t* faces,
                                   const float* verts_ndc, const float* verts_image, FaceState fs, const dm2_render_desc* pack,
-                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, hipStream_t st);
+                                  uint32_t* host_meta, uint32_t host_seq, uint2* ranges_to_clear, uint32_t* tile_order, hipStream_t st);
 // run: the sorted per-tile lists (renderer.cu:185-219): face_list ordered by (tile, depth key, emission order) + ranges.
 // key depth = depths or min_depths.  max_tile_entries (from the plan) picks the method: per-tile sorts in LDS, or -- lists
 // beyond TILE_SORT_MAX entries, or legacy = true -- the reference's way, one global stable radix sort.
 constexpr int64_t TILE_SORT_MAX = 32768;
 // ranges_cleared: the plan's last kernel has already zeroed `ranges` (launch_preprocess_scan's ranges_to_clear)
 hipError_t launch_bin_sort(int B, int F, int W, int H, int64_t R, int64_t max_tile_entries, bool legacy, const float* key_depth,
-                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, hipStream_t st);
+                           FaceState fs, BinningState bs, uint2* ranges, bool ranges_cleared, uint32_t* tile_order, hipStream_t st);
+
+// the composite kernels' block -> tile table in index order (a frame without faces: no plan ran)
+void launch_tile_order_identity(int64_t Tn, uint32_t* tile_order, hipStream_t st);
 
 void launch_render_forward_point(const dm2_render_desc& d, const uint2* ranges, const uint32_t* face_list, ImageState is,
                                  float* out_color, float* out_depth, int32_t* out_tri_cnt, uint64_t* hit_masks,

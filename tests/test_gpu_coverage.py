@@ -331,3 +331,40 @@ def test_backward_kernel_selection(route):
     # a second backward of the same forward (retain_graph): the tie queue's counters were left as they were found
     g2 = C.render_backward_cuda(out[0], *dargs, tgc, tgd, out[7], bin_buf, out[9], out[3], out[4], out[5], out[6])
     _check_grads([x.cpu().numpy() for x in g2], gref)
+
+
+# ---- the composite kernels' block -> tile order is only an order of execution ---------------------------------------------
+@pytest.mark.parametrize("temp", [1.0, 0.0])
+def test_tile_order_modes_render_the_same_frame(temp, monkeypatch):
+    """k_tile_order (dm2_binning.hip): index order, shortest quarter of every XCD band last, whole band longest list first --
+    every tile is rendered exactly once in each, so the images are bit-identical, equal to the oracle's, and the gradients
+    agree (their atomics' order differs).  A frame of 23 x 9 tiles (bands of 26 tiles, the last one short) with lists from
+    empty to long: faces crowd the left third."""
+    C, orc = _C(), _orc()
+    W, H, F = 360, 136, 900
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 77, depth_complexity=6.0)
+    # crowd the faces: two thirds of them squeezed into the left third of the frame (NDC x -> -1 + (x + 1) / 3)
+    v = sc.verts.clone()
+    k = scenes.TAN_HALF_FOV * (W / H)
+    depth = scenes.CAM_DIST - v[:, 2]
+    xn = v[:, 0] / (depth * k)
+    crowd = torch.arange(v.shape[0]) < 2 * F                          # (a soup: vertices 3 f .. 3 f + 2 belong to face f)
+    v[:, 0] = torch.where(crowd, (-1.0 + (xn + 1.0) / 3.0) * depth * k, v[:, 0])
+    sc.verts = v
+    args = capture_forward_args(sc, [0], [[0, 0]], W, H, temp, 20)[0]
+    dargs = _dev(args)
+    ref = orc.render_forward_cuda(*to_numpy_args(args))
+    rng = np.random.default_rng(9)
+    gc = rng.standard_normal(ref.color.shape).astype(np.float32); gd = rng.standard_normal(ref.depth.shape).astype(np.float32)
+    gref = orc.render_backward_cuda(ref, gc, gd)
+    tgc, tgd = torch.from_numpy(gc).cuda(), torch.from_numpy(gd).cuda()
+    images = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("DM2_TILE_ORDER_MODE", mode)
+        out = C.render_forward_cuda(*dargs)
+        g = C.render_backward_cuda(out[0], *dargs, tgc, tgd, out[7], out[8], out[9], out[3], out[4], out[5], out[6])
+        images.append((out[1].cpu().numpy(), out[2].cpu().numpy()))
+        assert np.array_equal(images[-1][0].view(np.uint32), ref.color.view(np.uint32)), mode
+        assert np.array_equal(images[-1][1].view(np.uint32), ref.depth.view(np.uint32)), mode
+        _check_grads([x.cpu().numpy() for x in g], gref)
+    monkeypatch.delenv("DM2_TILE_ORDER_MODE")

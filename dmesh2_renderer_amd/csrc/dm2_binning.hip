@@ -101,31 +101,83 @@ __device__ __forceinline__ uint32_t wave_count_tiles(uint32_t* cnt, uint32_t t, 
     return RANK ? wave_count_tiles_finish(p) : 0u;
 }
 
+// The plan kernel's two forms
+enum { PRE_LAYERS = 0,      // depth keys, cull, tile rectangles and counts (LayeredRenderer: no records, no pair bound)
+       PRE_FUSED = 1 };     // + the pair bound + the packed face records
+// (view, face) items per lane, 256 lanes apart, their operands fetched together.  One: with two the fused form needs 142 VGPRs
+// (3 waves per SIMD), and culling two per lane at twice the occupancy with the records packed by a kernel of their own
+// behind the scan is slower on every input tried (four 512 x 512 windows of 1080p cameras: plan 0.33 against 0.26 ms;
+// a 1/8 band of a 1080p frame 0.117 against 0.093 ms; the whole frame 0.173 against 0.136 ms).
+__host__ __device__ constexpr int pre_items(int) { return 1; }
+
+// A wave's records leave through LDS, a 128-B half at a time, so that every store instruction writes whole 128-B lines (8
+// lanes per line).  A lane storing its own record 16 B per instruction leaves 64 partially written lines per instruction
+// to the L2, which evicts part of them before the rest of the line arrives: WRITE_SIZE 386 MB for 296 MB of stores at cfg 4,
+// the plan 0.175 -> 0.133 ms without them.  Whole waves (every lane of the wave calls, `has`: the lane holds a record);
+// idx: the lane's record index, consecutive over the wave; sw: 8 KB of LDS of the wave's own.
+__device__ __forceinline__ void store_records(const FaceRec& r, bool has, unsigned long long tmask, int64_t idx, uint4* __restrict__ recs, uint4* sw) {
+    const uint4* src = reinterpret_cast<const uint4*>(&r);
+    const int lane = (int)(threadIdx.x & 63);
+    uint4* dst = recs + (idx - lane) * FACE_REC_U4;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sw[lane * 8 + (k ^ (lane & 7))] = src[half * 8 + k];    // (swizzled: 8 lanes cover the 32 banks)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int rr = j * 8 + (lane >> 3), c = lane & 7;
+            if ((tmask >> rr) & 1ull) dst[(int64_t)rr * FACE_REC_U4 + half * 8 + c] = sw[rr * 8 + (c ^ (rr & 7))];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
+
 // PACK: also write the face's packed record (dm2_stage.h) for the composite kernels -- only for faces that reach a
 // tile list.  `d` is read only then.  (A/B at cfg4: packing in a kernel of its own behind the plan's read-back, so that
 // it runs while the host sizes and enqueues the run step, costs more than it hides -- the binning part alone is bound by
 // its atomics, 0.08 ms, which here disappear behind the record traffic: 0.16 ms fused against 0.08 + 0.13 ms split.)
-#ifndef DM2_PRE_COALESCE
-#define DM2_PRE_COALESCE 1
-#endif
 #ifndef DM2_PRE_WAVES
 #define DM2_PRE_WAVES 1
 #endif
-template <bool PACK>
+template <int MODE>
 __global__ void __launch_bounds__(256, DM2_PRE_WAVES)
 k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __restrict__ patch_min,
              const int32_t* __restrict__ faces, const float* __restrict__ verts_ndc,
              const float* __restrict__ verts_image, FaceState fs, dm2_render_desc d) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * F) return;
+    // pre_items(MODE) (view, face) items per lane, 256 lanes apart: their vertex ids, then their image corners, fetched for
+    // all items before the first is looked at.  No lane leaves early (the records are stored by whole waves): invalid items
+    // (behind the last one) read the last item's operands and count as culled.
+    constexpr bool PACK = MODE == PRE_FUSED;
+    constexpr int DM2_PRE_ITEMS = pre_items(MODE);
+    const int64_t BF = (int64_t)B * F;
+    int64_t idx_[DM2_PRE_ITEMS]; int vid_[DM2_PRE_ITEMS][3]; float2 img_[DM2_PRE_ITEMS][3];
+#pragma unroll
+    for (int it = 0; it < DM2_PRE_ITEMS; it++) {
+        idx_[it] = ((int64_t)blockIdx.x * DM2_PRE_ITEMS + it) * 256 + threadIdx.x;
+        const int64_t ic = idx_[it] < BF ? idx_[it] : BF - 1;
+        const int f = (int)(ic % F);
+        vid_[it][0] = faces[3 * f]; vid_[it][1] = faces[3 * f + 1]; vid_[it][2] = faces[3 * f + 2];
+    }
+#pragma unroll
+    for (int it = 0; it < DM2_PRE_ITEMS; it++) {
+        const int64_t ic = idx_[it] < BF ? idx_[it] : BF - 1;
+        const float* img = verts_image + (ic / F) * P * 2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) img_[it][k] = *reinterpret_cast<const float2*>(img + 2 * vid_[it][k]);
+    }
+#pragma unroll
+    for (int it = 0; it < DM2_PRE_ITEMS; it++) {
+    const bool valid = idx_[it] < BF;
+    if (!__ballot(valid)) break;                                              // (wave-uniform)
+    const int64_t idx = valid ? idx_[it] : BF - 1;
     const int b = (int)(idx / F), f = (int)(idx % F);
     const uint32_t pmx = patch_min ? (uint32_t)patch_min[2 * b] : 0u, pmy = patch_min ? (uint32_t)patch_min[2 * b + 1] : 0u;
-    const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
+    const int v0 = vid_[it][0], v1 = vid_[it][1], v2 = vid_[it][2];
     const float* ndc = verts_ndc + (int64_t)b * P * 3;
-    const float* img = verts_image + (int64_t)b * P * 2;
-    const float2 i0 = *reinterpret_cast<const float2*>(img + 2 * v0);
-    const float2 i1 = *reinterpret_cast<const float2*>(img + 2 * v1);
-    const float2 i2 = *reinterpret_cast<const float2*>(img + 2 * v2);
+    const float2 i0 = img_[it][0], i1 = img_[it][1], i2 = img_[it][2];
 
     // The tile rectangle first (forward.cu:77-88), the depth cull (forward.cu:71) only for faces that have one: a face has
     // to pass both, and most (view, face) items of a window or of a rank's band fail this one -- their NDC z is never fetched.
@@ -134,7 +186,7 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
     {
         uint32_t x0, y0, x1, y1;
         patch_rect_from_tri(pmx, pmy, i0.x, i0.y, i1.x, i1.y, i2.x, i2.y, gx, gy, x0, y0, x1, y1);
-        touched = (y1 - y0) * (x1 - x0);                                   // forward.cu:88,93
+        touched = valid ? (y1 - y0) * (x1 - x0) : 0u;                      // forward.cu:88,93
         if (touched != 0) {
             const float z0 = ndc[3 * v0 + 2], z1 = ndc[3 * v1 + 2], z2 = ndc[3 * v2 + 2];
             const float max_z = fmaxf(fmaxf(z0, z1), z2);
@@ -180,7 +232,7 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             }
         }
     }
-    if (PACK) {
+    if (MODE != PRE_LAYERS) {
         // Upper bound of the (pixel, face) pairs the forward composite will enumerate for this face: the patch pixels whose
         // unit square passes the clipper's bounding-box test (aa.h:96-101; dm2_pairs.h face_pixel_rect, tile by tile).  The
         // sum over the faces sizes the forward's pair pool (dm2_state.h), read back with num_rendered.
@@ -205,52 +257,27 @@ k_preprocess(int B, int P, int F, uint32_t gx, uint32_t gy, const int32_t* __res
             if (tot) atomicAdd(fs.pair_part + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (PAIR_PARTS - 1)), tot);
         }
     }
-    fs.tiles_touched[idx] = touched;
-    fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
-    fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
-#if DM2_PRE_COALESCE
-    // The records leave through LDS, a 128-B half at a time, so that every store instruction writes whole 128-B lines (8 lanes
-    // per line).  A lane storing its own record 16 B per instruction leaves 64 partially written lines per instruction to the
-    // L2, which evicts part of them before the rest of the line arrives: WRITE_SIZE 386 MB for 296 MB of stores at cfg 4.
-    __shared__ uint4 s_t[PACK ? 4 : 1][PACK ? 64 * 8 : 1];
-    const unsigned long long tmask = __ballot(touched != 0);
-    if (PACK && tmask != 0ull && __ballot(true) == ~0ull) {                // (whole waves; wave-uniform)
-        FaceRec r;
-        if (touched != 0) { pack_face(d, b, f, i1, r); r.pad[0] = 0.f; }
-        const uint4* src = reinterpret_cast<const uint4*>(&r);
-        const int lane = (int)(threadIdx.x & 63);
-        uint4* sw = s_t[threadIdx.x >> 6];
-        uint4* dst = fs.recs + (idx - lane) * FACE_REC_U4;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            if (touched != 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) sw[lane * 8 + (k ^ (lane & 7))] = src[half * 8 + k];    // (swizzled: 8 lanes cover the 32 banks)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int rr = j * 8 + (lane >> 3), c = lane & 7;
-                if ((tmask >> rr) & 1ull) dst[(int64_t)rr * FACE_REC_U4 + half * 8 + c] = sw[rr * 8 + (c ^ (rr & 7))];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (valid) fs.tiles_touched[idx] = touched;
+    if (touched != 0) {      // (as the reference, forward.cu:71-72,88-89: a culled face leaves these unwritten; their readers look at tiles_touched first)
+        fs.depths[idx] = d01; fs.min_depths[idx] = dmin; fs.max_depths[idx] = dmax;
+        fs.rect_lo[idx] = lo; fs.rect_hi[idx] = hi;
+    }
+    if (PACK) {
+        __shared__ uint4 s_t[PACK ? 4 : 1][PACK ? 64 * 8 : 1];
+        const unsigned long long tmask = __ballot(touched != 0);
+        if (tmask != 0ull) {                                               // (wave-uniform)
+            FaceRec r;
+            if (touched != 0) { pack_face(d, b, f, i1, r); r.pad[0] = 0.f; }
+            store_records(r, touched != 0, tmask, idx_[it], fs.recs, s_t[threadIdx.x >> 6]);   // (the unclamped index: every lane derives the wave's first record from its own)
         }
-    } else
-#endif
-    if (PACK && touched != 0) {
-        FaceRec r;
-        pack_face(d, b, f, i1, r);
-        r.pad[0] = 0.f;
-        const uint4* src = reinterpret_cast<const uint4*>(&r);
-        uint4* dst = fs.recs + idx * FACE_REC_U4;
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(FaceRec) / 16); k++) dst[k] = src[k];
     }
     if (any_small) {                                                       // (wave-uniform: the shuffles need the whole wave)
         const uint32_t r0 = wave_count_tiles_finish(place[0]), r1 = wave_count_tiles_finish(place[1]);
         const uint32_t r2 = wave_count_tiles_finish(place[2]), r3 = wave_count_tiles_finish(place[3]);
         if (small) fs.tile_rank[idx] = make_uint4(r0, r1, r2, r3);
     }
+    __builtin_amdgcn_sched_barrier(0);                                      // (one item after the other: interleaved they need 142 VGPRs, 3 waves per SIMD)
+    }   // items
 }
 
 // Exclusive scan of the tile counts, their sum and maximum.  One block; 8192 tiles (a 1080p frame) per round: coalesced
@@ -621,14 +648,15 @@ hipError_t launch_preprocess_scan(int B, int P, int F, int W, int H, const int32
     if (BF == 0) return hipSuccess;
     const uint32_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int64_t Tn = (int64_t)B * gx * gy;
-    const int blocks = (int)((BF + 255) / 256);
     StageTimer tm(ST_PREP, st);
     if (Tn == 0) return hipMemsetAsync(fs.plan_meta, 0, 4 * sizeof(uint32_t), st);
     launch_zero_words(fs.tile_cnt, 2 * Tn + 2 * PAIR_PARTS, st);           // (the tile counts and the pair-bound partial sums; k_tile_scan writes plan_meta)
-    if (pack && fs.recs)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
+    const int mode = pack && fs.recs ? PRE_FUSED : PRE_LAYERS;
+    const int blocks = (int)((BF + 256 * pre_items(mode) - 1) / (256 * pre_items(mode)));
+    if (mode == PRE_FUSED)
+        hipLaunchKernelGGL(k_preprocess<PRE_FUSED>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs, *pack);
     else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
+        hipLaunchKernelGGL(k_preprocess<PRE_LAYERS>, dim3(blocks), dim3(256), 0, st, B, P, F, gx, gy, patch_min, faces, verts_ndc, verts_image, fs,
                            dm2_render_desc{});
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, Tn, fs.tile_cnt, fs.tile_cnt_big, fs.tile_start, fs.pair_part, fs.plan_meta,
                        host_meta, host_seq, ranges_to_clear);

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import ROOT, capture_forward_args, rel_linf, scenes, to_numpy_args
+from util import ROOT, capture_forward_args, rel_linf, scenes, soup_args, to_numpy_args
 
 pytestmark = pytest.mark.gpu
 
@@ -368,3 +368,22 @@ def test_tile_order_modes_render_the_same_frame(temp, monkeypatch):
         assert np.array_equal(images[-1][1].view(np.uint32), ref.depth.view(np.uint32)), mode
         _check_grads([x.cpu().numpy() for x in g], gref)
     monkeypatch.delenv("DM2_TILE_ORDER_MODE")
+
+
+def test_plan_records_of_partial_waves_and_windows():
+    """The plan's packed face records are stored by whole waves through LDS (dm2_binning.hip store_records): item counts that
+    are no multiple of 64, windows whose items mostly have no tile, two views -- the frame is bit for bit the oracle's and the
+    gradients agree (a record written to the wrong place or not at all shows in both)."""
+    C, orc = _C(), _orc()
+    for args in (_soup(200, 120, 701, 31, 1.0),                                            # the whole frame, 701 = 10 * 64 + 61 items
+                 soup_args(256, 192, 900, scenes.SEED_BASE + 32, cams=2, batch_idx=(0, 1), patch_min=[[40, 30], [130, 64]], pw=96, ph=80)[0]):   # two windows
+        dargs = _dev(args)
+        ref = orc.render_forward_cuda(*to_numpy_args(args))
+        rng = np.random.default_rng(10)
+        gc = rng.standard_normal(ref.color.shape).astype(np.float32); gd = rng.standard_normal(ref.depth.shape).astype(np.float32)
+        gref = orc.render_backward_cuda(ref, gc, gd)
+        out = C.render_forward_cuda(*dargs)
+        assert np.array_equal(out[1].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+        assert np.array_equal(out[2].cpu().numpy().view(np.uint32), ref.depth.view(np.uint32))
+        g = C.render_backward_cuda(out[0], *dargs, torch.from_numpy(gc).cuda(), torch.from_numpy(gd).cuda(), out[7], out[8], out[9], out[3], out[4], out[5], out[6])
+        _check_grads([x.cpu().numpy() for x in g], gref)

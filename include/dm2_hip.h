@@ -108,8 +108,7 @@ enum {
     DM2_SCRATCH_FACE = 0,     /* count = B*F, aux = 2 * (B*tiles) + 1 for Renderer (holds the packed face records,
                                  256 B per (view, face), that forward AND backward read), 2 * (B*tiles) for
                                  LayeredRenderer; tiles = ceil(W/16) * ceil(H/16) */
-    DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles: per pixel what the backward needs from the forward, per tile its list
-                                 range and the order in which the composite kernels take the tiles */
+    DM2_SCRATCH_IMAGE = 1,    /* count = B*H*W, aux = B*tiles      */
     DM2_SCRATCH_BINNING = 2,  /* count = num_rendered, aux = B*tiles */
     DM2_SCRATCH_LAYER_IMAGE = 3, /* count = B*H*W, aux = B*tiles    */
     DM2_SCRATCH_LAYER_TETS = 4,  /* count = T (tets): packed per-tet records of the layer walk, 256 B each */

@@ -1,4 +1,4 @@
-# A/B of builds: usage: bash tools/ab_pre.sh "<lib> <lib> ..." "<bench args>;<bench args>;..."
+# A/B of builds: usage: bash tools/ab_libs.sh "<lib> <lib> ..." "<bench args>;<bench args>;..."
 LIBS=${1:-dmesh2_renderer_amd/csrc/libdm2_hip.so}
 IFS=';' read -ra RUNS <<< "${2:---config cfg4}"
 for args in "${RUNS[@]}"; do for i in 1 2; do for lib in $LIBS; do

@@ -522,6 +522,10 @@ k_aa_ties(dm2_render_desc d, const uint4* __restrict__ face_recs, const TieEntry
           uint32_t* __restrict__ counters, float* __restrict__ dL_daa_face_verts, bool check_mode) {
     if (check_mode && counters[0] != 3u) return;
     const uint32_t n = min(counters[2], cap);
+    // the grid is sized for a full queue; the blocks behind the queue's end leave without a ticket (1024 tickets on one
+    // address are serialised by the L2 in front of the working blocks' atomics: 8 us of a 0.2-ms step at cfg 1)
+    const uint32_t working = min(gridDim.x, (n + blockDim.x - 1u) / blockDim.x);
+    if (blockIdx.x >= working) return;
     const bool to_verts = (d.flags & DM2_FLAG_AA_GRAD_TO_VERTS) != 0;
     // (wave-uniform trip count: the lanes of a wave reduce over runs of equal faces with DPP before the atomics -- a face's ties
     // come from neighbouring lanes of one wave of the main kernel and sit next to each other in the queue)
@@ -580,7 +584,7 @@ k_aa_ties(dm2_render_desc d, const uint4* __restrict__ face_recs, const TieEntry
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = atomicAdd(counters + 3, 1u);
     __syncthreads();
-    if (s_ticket == gridDim.x - 1 && threadIdx.x == 0) { counters[2] = 0u; counters[3] = 0u; }
+    if (s_ticket == working - 1 && threadIdx.x == 0) { counters[2] = 0u; counters[3] = 0u; }
 }
 
 // check_mode: the caller does not know what the forward left (DM2_FWD_UNKNOWN): both kernels look at hit_valid themselves

@@ -295,6 +295,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     __shared__ unsigned long long s_pairs, s_total64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) { s_max = 0; s_pairs = 0ull; s_total64 = 0ull; }
+    unsigned long long pair_sum = pair_part[tid];          // (requested first: it travels while the counts are scanned)
     uint32_t carry = 0, mx = 0;
     for (int64_t base = 0; base < Tn; base += ROUND) {
 #pragma unroll
@@ -338,7 +339,7 @@ k_tile_scan(int64_t Tn, const uint32_t* __restrict__ cnt, const uint32_t* __rest
     if (mx) atomicMax(&s_max, mx);
     {   // the pair bound: one partial sum per thread (PAIR_PARTS == blockDim.x), summed over the block
         static_assert(PAIR_PARTS == 1024, "one partial sum per thread of k_tile_scan");
-        unsigned long long v = pair_part[tid];
+        unsigned long long v = pair_sum;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
         if (lane == 0 && v) atomicAdd(&s_pairs, v);

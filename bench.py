@@ -46,6 +46,9 @@ CONFIGS = {
     "cfg4_b4": (1920, 1080, 1_000_000, 4),
     # large triangles, depth complexity 60 (SURVEY 8(d) generator with 15 x the coverage): most pairs are fully covered
     "cfg1_dc60": (256, 256, 2_000 * 15, 1),
+    # the cfg4 triangles with their faces (and the soup's vertices) in the order of the 16 x 16 tile of their centroid instead of
+    # at random: what a mesh whose face order follows space looks like to the memory system (a diagnostic, not a BASELINE config)
+    "cfg4_sorted": (1920, 1080, 1_000_000, 4),
 }
 VIEWS = {"cfg4_b4": dict(cams=4, pw=512, ph=512, pm=[[0, 0], [704, 284], [1408, 568], [640, 0]])}
 DEPTH_COMPLEXITY = {"cfg1_dc60": 60.0}
@@ -69,6 +72,25 @@ AA_TEMPERATURE = 1.0      # --aa-temperature; 1.0 is the BASELINE workload
 _LAST = {}                # the scene behind the last build_inputs() (host-prep inputs of the multi-GPU step)
 
 
+def spatially_sorted(sc):
+    """The soup with its faces ordered by the tile of their centroid (row-major tiles), vertices 3 f .. 3 f + 2 following."""
+    from dmesh2_renderer_amd import scenes
+    F = sc.faces.shape[0]
+    v = sc.verts.reshape(F, 3, 3)
+    c = v.mean(1)
+    depth = scenes.CAM_DIST - c[:, 2]
+    t = scenes.TAN_HALF_FOV
+    px = (c[:, 0] / (depth * t * sc.width / sc.height) + 1.0) * 0.5 * sc.width
+    py = (c[:, 1] / (depth * t) + 1.0) * 0.5 * sc.height
+    key = (py / 16).floor().clamp(0, 1e6).long() * 4096 + (px / 16).floor().clamp(0, 4095).long()
+    perm = torch.argsort(key, stable=True)
+    sc.verts = v[perm].reshape(-1, 3).contiguous()
+    sc.verts_color = sc.verts_color.reshape(F, 3, 3)[perm].reshape(-1, 3).contiguous()
+    sc.faces_opacity = sc.faces_opacity[perm].contiguous()
+    sc.faces_intense = sc.faces_intense[:, perm].contiguous()
+    return sc
+
+
 def build_inputs(cfg, device, rank, world):
     from dmesh2_renderer_amd import scenes
     import dmesh2_renderer_amd as dm2
@@ -79,7 +101,10 @@ def build_inputs(cfg, device, rank, world):
     if cfg in DEPTH_COMPLEXITY:
         # (the generator sizes the triangles for a mean depth complexity of 4 at F faces: same triangles, 15 x as many)
         kw["depth_complexity"] = DEPTH_COMPLEXITY[cfg]
-    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci, **kw).to(device)
+    sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + ci, **kw)
+    if cfg == "cfg4_sorted":
+        sc = spatially_sorted(sc)
+    sc = sc.to(device)
     _LAST["scene"] = sc
     got = {}
     real = _C.render_forward_cuda

@@ -66,6 +66,28 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
     const f3 ro0 = {s_ro[0], s_ro[1], s_ro[2]};
     const bool quick = __syncthreads_and(!inside || (ro.x == ro0.x && ro.y == ro0.y && ro.z == ro0.z &&
                                                      fabsf(rd.x) <= 1.0001f && fabsf(rd.y) <= 1.0001f && fabsf(rd.z) <= 1.0001f)) != 0;
+    // Strip prefilter (quick rays only).  A wave's 64 pixels are a strip of 16 x 4; its ray directions fill a small box
+    // [dc - dh, dc + dh].  The per-pixel quick test rejects on linear forms of the direction (A . rd, Bv . rd, Nn . rd and their
+    // sum), so a form's range over the box -- centre value +- sum |coefficient| x half-width -- decides for the whole strip at
+    // once: one lane per face, 64 faces per pass, and the per-pixel walk below only visits the faces some pixel of the strip may
+    // still be near (a third of a tile's list).  Conservative by construction: it only skips a face if EVERY pixel's quick test
+    // would reject it, with 10 % of the quick test's own margins to spare for the rounding of both evaluations.
+    float dcx = 0.f, dcy = 0.f, dcz = 0.f, dhx = 0.f, dhy = 0.f, dhz = 0.f;
+    if (quick) {
+        const float BIG = 3.0e38f;
+        float lx0 = inside ? rd.x : BIG, hx0 = inside ? rd.x : -BIG, ly0 = inside ? rd.y : BIG, hy0 = inside ? rd.y : -BIG;
+        float lz0 = inside ? rd.z : BIG, hz0 = inside ? rd.z : -BIG;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lx0 = fminf(lx0, __shfl_xor(lx0, o)); hx0 = fmaxf(hx0, __shfl_xor(hx0, o));
+            ly0 = fminf(ly0, __shfl_xor(ly0, o)); hy0 = fmaxf(hy0, __shfl_xor(hy0, o));
+            lz0 = fminf(lz0, __shfl_xor(lz0, o)); hz0 = fmaxf(hz0, __shfl_xor(hz0, o));
+        }
+        if (hx0 >= lx0) {                                               // (a strip with a pixel inside the image)
+            dcx = 0.5f * (lx0 + hx0); dcy = 0.5f * (ly0 + hy0); dcz = 0.5f * (lz0 + hz0);
+            dhx = 0.5001f * (hx0 - lx0) + 1.0e-7f; dhy = 0.5001f * (hy0 - ly0) + 1.0e-7f; dhz = 0.5001f * (hz0 - lz0) + 1.0e-7f;
+        }
+    }
     bool done = !inside;
     float pT = 1.0f, T = 1.0f;
     uint32_t contributor = 0, last_contributor = 0;
@@ -92,8 +114,37 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
         }
         __syncthreads();
 
-        for (int j = 0; j < n; j++) {
-            contributor++;
+        for (int sub = 0; sub < FP_CHUNK / 64; sub++) {
+        if (64 * sub >= n) break;
+        unsigned long long todo;
+        {
+            const int jf = 64 * sub + lane;
+            bool keep = jf < n;
+            if (quick && jf < n) {
+                const FpQuick& q = s_quick[jf];
+                const float ac = __builtin_fmaf(dcx, q.A[0], __builtin_fmaf(dcy, q.A[1], dcz * q.A[2]));
+                const float bc = __builtin_fmaf(dcx, q.Bv[0], __builtin_fmaf(dcy, q.Bv[1], dcz * q.Bv[2]));
+                const float nc = __builtin_fmaf(dcx, q.Nn[0], __builtin_fmaf(dcy, q.Nn[1], dcz * q.Nn[2]));
+                const float ar = dhx * fabsf(q.A[0]) + dhy * fabsf(q.A[1]) + dhz * fabsf(q.A[2]);
+                const float br = dhx * fabsf(q.Bv[0]) + dhy * fabsf(q.Bv[1]) + dhz * fabsf(q.Bv[2]);
+                const float nr = dhx * fabsf(q.Nn[0]) + dhy * fabsf(q.Nn[1]) + dhz * fabsf(q.Nn[2]);
+                const float g0 = q.A[0] + q.Bv[0] - q.Nn[0], g1 = q.A[1] + q.Bv[1] - q.Nn[1], g2 = q.A[2] + q.Bv[2] - q.Nn[2];
+                const float gc = __builtin_fmaf(dcx, g0, __builtin_fmaf(dcy, g1, dcz * g2));
+                const float gr = dhx * fabsf(g0) + dhy * fabsf(g1) + dhz * fabsf(g2) + 1.0e-6f * (fabsf(q.A[0]) + fabsf(q.A[1]) + fabsf(q.A[2]) + fabsf(q.Bv[0]) + fabsf(q.Bv[1]) + fabsf(q.Bv[2]) + fabsf(q.Nn[0]) + fabsf(q.Nn[1]) + fabsf(q.Nn[2]));
+                const float ma = 1.1f * q.ma, mb = 1.1f * q.mb, md = 1.1f * q.md, M = 1.1f * (q.ma + q.mb + q.md);
+                bool rej = false;
+                if (nc - nr > md) rej = (ac + ar < -ma) || (bc + br < -mb) || (gc - gr > M);          // the denominator positive all over the strip
+                else if (nc + nr < -md) rej = (ac - ar > ma) || (bc - br > mb) || (gc + gr < -M);     // negative all over the strip
+                keep = !rej;                                                                           // (a NaN anywhere keeps the face)
+            }
+            todo = __ballot(keep);
+            // the faces the strip skips blend into none of its pixels
+            if (jf < n && !keep) hit_masks[((int64_t)range.x + base + jf) * 4 + wid] = 0ull;
+        }
+        while (todo) {
+            const int j = 64 * sub + (__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            contributor = (uint32_t)(base + j) + 1u;                    // the entry's 1-based position in the tile's list (forward.cu:310)
             if (quick) {
                 // numerators and denominator of (u, v) up to rounding, and how far the reference's own evaluation can be from them
                 const FpQuick& q = s_quick[j];
@@ -138,6 +189,7 @@ k_render_forward_point(dm2_render_desc d, const uint2* __restrict__ ranges, cons
                 if (T < T_EPS) done = true;
             }
         }
+        }   // sub-chunks of 64 faces
     }
 
     // the tile's largest n_contrib: where the backward's walk starts (dm2_backward_fast.hip)

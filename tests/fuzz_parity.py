@@ -29,6 +29,8 @@ def one_case(seed, idx, verbose=False):
     F = int(rng.choice([1, 7, 60, 400, 2500, 9000]))
     dc = float(rng.choice([0.3, 1.5, 4.0, 12.0, 40.0, 120.0]))
     temp = float(rng.choice([1.0, 1.0, 0.5, 0.25, 0.0]))
+    if os.environ.get("DM2_FUZZ_TEMP0") == "1":              # a sweep of the point-sampled path only (the draw above still happens: same scenes)
+        temp = 0.0
     K = int(rng.choice([0, 3, 20]))
     cams = int(rng.integers(1, 3))
     sc = scenes.triangle_soup(W, H, F, scenes.SEED_BASE + 1000 + idx + 7919 * seed, num_cams=cams, shared_verts=bool(rng.integers(0, 2)),

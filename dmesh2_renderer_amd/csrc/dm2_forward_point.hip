@@ -18,6 +18,8 @@
 // within the bound of the triangle does the wave run the reference's arithmetic (~60 instructions), which alone decides
 // and alone produces values.  Bit-identical output.  (Measured at 1080p / 1 M faces: a first version that carried the
 // magnitudes per component -- 39 instructions + 8 LDS reads per test -- gained nothing over the exact test alone.)
+// In front of both, once per chunk and wave: the same linear forms over the BOX of the strip's ray directions, one lane per
+// face (see "Strip prefilter" in the kernel) -- the walk visits only the faces some pixel of the strip may be near.
 #include <hip/hip_runtime.h>
 
 #include "dm2_device_math.h"
